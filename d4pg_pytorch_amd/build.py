@@ -1,0 +1,99 @@
+"""Builds the native code in-tree.
+
+* ``csrc/libd4pg_hip.so``  — HIP kernels, ``hipcc --offload-arch=gfx950`` (cross-compiles
+  without a GPU).  Objects are linked against the HIP runtime that PyTorch itself
+  loads (``torch/lib/libamdhip64.so``), never a second copy: stream handles and
+  device pointers are shared with torch.
+* ``csrc/libd4pg_host.so`` — C++ host runtime (shared-memory transition rings,
+  seq-locked weight slab, n-step assembler, OU noise, CPU actor inference), ``g++``.
+
+Run ``python -m d4pg_pytorch_amd.build`` or call :func:`build_all`.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from typing import List
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+HIP_SOURCES = ["gemm.hip", "loss.hip", "optim.hip", "replay.hip", "nstep.hip"]
+HOST_SOURCES = ["host_runtime.cpp"]
+HIP_LIB = os.path.join(CSRC, "libd4pg_hip.so")
+HOST_LIB = os.path.join(CSRC, "libd4pg_host.so")
+ARCH = "gfx950"
+
+
+def _run(cmd: List[str]) -> None:
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError(f"command failed: {' '.join(cmd)}\n{proc.stdout}")
+
+
+def _stale(target: str, sources: List[str]) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def torch_lib_dir() -> str:
+    import torch
+    return os.path.join(os.path.dirname(torch.__file__), "lib")
+
+
+def build_hip(force: bool = False, verbose: bool = False) -> str:
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
+    deps = srcs + [os.path.join(CSRC, "common.h")]
+    if not force and not _stale(HIP_LIB, deps):
+        return HIP_LIB
+    objdir = os.path.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+    objs = []
+    hipcc = _hipcc()
+    for s in srcs:
+        o = os.path.join(objdir, os.path.basename(s) + ".o")
+        if force or _stale(o, [s, os.path.join(CSRC, "common.h")]):
+            cmd = [hipcc, "-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            _run(cmd)
+        objs.append(o)
+    tl = torch_lib_dir()
+    tmp = HIP_LIB + ".tmp"
+    _run(["g++", "-shared", "-o", tmp] + objs + [f"-L{tl}", "-l:libamdhip64.so"])
+    os.replace(tmp, HIP_LIB)
+    return HIP_LIB
+
+
+def build_host(force: bool = False, verbose: bool = False) -> str:
+    srcs = [os.path.join(CSRC, s) for s in HOST_SOURCES]
+    if not force and not _stale(HOST_LIB, srcs):
+        return HOST_LIB
+    tmp = HOST_LIB + ".tmp"
+    cmd = ["g++", "-O3", "-march=x86-64-v3", "-fPIC", "-shared", "-std=c++17", "-pthread", "-fopenmp-simd"] + srcs + \
+          ["-o", tmp, "-lrt"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    _run(cmd)
+    os.replace(tmp, HOST_LIB)
+    return HOST_LIB
+
+
+def build_all(force: bool = False, verbose: bool = False) -> None:
+    build_host(force, verbose)
+    build_hip(force, verbose)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv, verbose=True)
+    print("built:", HIP_LIB, HOST_LIB)

@@ -1,0 +1,108 @@
+// Shared declarations for the gfx950 (MI355X / CDNA4) learner kernels.
+//
+// Everything here is written for 64-lane wavefronts and the f32-input MFMA
+// (v_mfma_f32_32x32x2_f32).  There is no other target.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define D4PG_API extern "C" __attribute__((visibility("default")))
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kWave = 64;
+
+// ---------------------------------------------------------------------------
+// Device-resident learner state.  Kernel arguments are frozen when the update
+// is captured into a HIP graph, so everything that changes from one update to
+// the next (step counters, bias corrections, replay cursor, RNG stream) lives
+// in this struct in device memory and is advanced by the kernels themselves.
+//
+// Race-free by construction: every field is written by exactly one thread of a
+// kernel in which no thread reads that field.
+//   step_done  : read by the first kernel of an update, written by the last.
+//   step_cur   : written by the first kernel (= step_done + 1), read by the rest.
+//   bc1, bc2   : Adam bias corrections for step_cur, written by the first kernel.
+// ---------------------------------------------------------------------------
+struct DevState {
+    long long step_done;      // completed updates
+    long long step_cur;       // 1-based index of the update in flight
+    float bc1;                // 1 - beta1^step_cur
+    float bc2;                // 1 - beta2^step_cur
+    float per_beta;           // importance exponent used for the batch in flight
+    float max_priority;       // running max of raw priorities (PER), >= 1
+    long long replay_size;    // valid rows in the replay shard
+    long long replay_head;    // next row to overwrite
+    unsigned long long seed;  // RNG seed
+    long long inserted_total; // rows ever inserted
+    long long pad_[2];
+};
+
+// Device metric accumulator layout (floats).
+enum { MET_VALUE_LOSS = 0, MET_POLICY_LOSS = 1, MET_COUNT = 2, MET_Q_MEAN = 3 };
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Philox-4x32-10 counter-based generator (one call = 4 x 32 random bits).
+__device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                           uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// uniform double in [0,1) from 53 random bits
+__device__ __forceinline__ double u01_from_bits(uint32_t hi, uint32_t lo) {
+    const uint64_t x = (((uint64_t)hi << 32) | lo) >> 11;
+    return (double)x * (1.0 / 9007199254740992.0);
+}
+
+// Advance the step counter / Adam bias corrections (single thread).  Reads
+// step_done, writes step_cur, bc1, bc2, per_beta: the same contract as the
+// tick embedded in the replay-sampling kernel.
+static __device__ __forceinline__ void devstate_tick(DevState* st, float beta1, float beta2, float per_b0, float per_b1,
+                              long long total_steps) {
+    const long long t = st->step_done + 1;
+    st->step_cur = t;
+    st->bc1 = (float)(1.0 - pow((double)beta1, (double)t));
+    st->bc2 = (float)(1.0 - pow((double)beta2, (double)t));
+    double frac = (double)st->step_done / (double)(total_steps > 0 ? total_steps : 1);
+    frac = frac < 0.0 ? 0.0 : (frac > 1.0 ? 1.0 : frac);
+    st->per_beta = (float)(per_b0 + frac * (per_b1 - per_b0));
+}
+
+
+#define HIP_CHECK_RET(expr)                                   \
+    do {                                                      \
+        hipError_t e_ = (expr);                               \
+        if (e_ != hipSuccess) return (int)e_;                 \
+    } while (0)

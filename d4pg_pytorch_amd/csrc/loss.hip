@@ -1,0 +1,306 @@
+// Fused loss kernels of the learner update (gfx950, one 64-lane wave per batch row).
+//
+//  d4pg_critic_loss_kernel : softmax(target logits) -> categorical projection of r + g*z
+//                            -> softmax(online logits) -> BCE (reference) or CE loss
+//                            -> per-sample loss, PER priority, dlogits, metric.
+//  d4pg_actor_loss_kernel  : softmax(logits) . z -> expected Q, policy-loss metric and
+//                            dlogits = -(1/B) p (z - q).
+//  d3pg_critic_loss_kernel : y = clip(r + (1-d) g Q'), per-sample (Q-y)^2, priority, dQ.
+//
+// Math (written from the definitions, see also ops/ref.py):
+//   z_j = v_min + j dz;  beta_j = (clip(r + (1-d) g z_j) - v_min)/dz;
+//   m_i = sum_j p_j max(0, 1 - |beta_j - i|)            (dense, atomics-free projection)
+//   BCE: L = (1/N) sum_i -[m_i max(log q_i,-100) + (1-m_i) max(log(1-q_i),-100)]
+//        dL/dlogit_i = q_i (g_i - sum_k g_k q_k),  g_i = (1/N)(-(m_i/q_i)[log q_i>-100] + ((1-m_i)/(1-q_i))[log(1-q_i)>-100])
+//   CE : L = -sum_i m_i log q_i;  dL/dlogit_i = q_i sum(m) - m_i
+#include "common.h"
+
+constexpr int MAX_ATOM_SLOTS = 4;   // supports up to 256 atoms (4 per lane); kernels are instantiated per slot count
+
+struct D4pgLossArgs {
+    const float* logits_t;   // [B, ld] target-critic logits at (s', pi'(s'))
+    const float* logits;     // [B, ld] online-critic logits at (s, a)
+    const float* reward;     // [B]
+    const float* done;       // [B]
+    const float* gamma;      // [B] per-sample discount**k (ignored if fixed_gamma >= 0)
+    const float* weights;    // [B] importance weights or null
+    float* dlogits;          // [B, ld]
+    float* per_loss;         // [B]
+    float* priority;         // [B]
+    float* proj_out;         // [B, ld] optional: projected target (tests), may be null
+    float* metrics;          // device metric accumulator
+    int B, N, ld;
+    int use_ce;
+    float v_min, v_max;
+    float fixed_gamma;       // < 0: use per-sample gamma
+    float inv_B;             // 1 / (global batch) — gradient scale
+};
+
+template <int SLOTS>
+__global__ __launch_bounds__(256) void d4pg_critic_loss_kernel(const D4pgLossArgs a) {
+    __shared__ float s_p[4][256];
+    __shared__ float s_beta[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= a.B) return;   // whole wave exits together (no block-level barrier below)
+    const int N = a.N;
+    const float dz = (a.v_max - a.v_min) / (float)(N - 1);
+    const float r = a.reward[b];
+    const float nd = 1.f - a.done[b];
+    const float g = a.fixed_gamma >= 0.f ? a.fixed_gamma : a.gamma[b];
+    const float w = a.weights ? a.weights[b] : 1.f;
+    float* sp = s_p[wave];
+    float* sb = s_beta[wave];
+
+    // ---- target softmax + beta_j ----
+    float lt[SLOTS], lo[SLOTS];
+    float mx_t = -INFINITY, mx_o = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int j = lane + 64 * s;
+        lt[s] = j < N ? a.logits_t[(size_t)b * a.ld + j] : -INFINITY;
+        lo[s] = j < N ? a.logits[(size_t)b * a.ld + j] : -INFINITY;
+        mx_t = fmaxf(mx_t, lt[s]);
+        mx_o = fmaxf(mx_o, lo[s]);
+    }
+    mx_t = wave_max(mx_t);
+    mx_o = wave_max(mx_o);
+    float sum_t = 0.f, sum_o = 0.f;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int j = lane + 64 * s;
+        lt[s] = j < N ? __expf(lt[s] - mx_t) : 0.f;
+        lo[s] = j < N ? __expf(lo[s] - mx_o) : 0.f;
+        sum_t += lt[s];
+        sum_o += lo[s];
+    }
+    sum_t = wave_sum(sum_t);
+    sum_o = wave_sum(sum_o);
+    const float inv_t = 1.f / sum_t, inv_o = 1.f / sum_o;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int j = lane + 64 * s;
+        if (j < N) {
+            const float z = a.v_min + dz * (float)j;
+            float tz = r + nd * g * z;
+            tz = fminf(a.v_max, fmaxf(a.v_min, tz));
+            sp[j] = lt[s] * inv_t;
+            sb[j] = (tz - a.v_min) / dz;
+        }
+    }
+    // LDS rows are private to this wave; wave-level execution order suffices,
+    // the builtin keeps the compiler from reordering the LDS accesses.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- dense projection: lane owns destination atoms i = lane + 64 s ----
+    float m[SLOTS];
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) m[s] = 0.f;
+    for (int j = 0; j < N; ++j) {
+        const float pj = sp[j], bj = sb[j];   // LDS broadcast reads
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            const float i = (float)(lane + 64 * s);
+            m[s] += pj * fmaxf(0.f, 1.f - fabsf(bj - i));
+        }
+    }
+
+    // ---- loss + gradient ----
+    float q[SLOTS], gi[SLOTS];
+    float loss = 0.f, gq = 0.f, msum = 0.f;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int i = lane + 64 * s;
+        q[s] = lo[s] * inv_o;
+        gi[s] = 0.f;
+        if (i < N) {
+            if (a.proj_out) a.proj_out[(size_t)b * a.ld + i] = m[s];
+            if (a.use_ce) {
+                // log q from the log-sum-exp form (finite even when q underflows)
+                const float logq = logf(lo[s] > 0.f ? lo[s] : 1e-45f) - logf(sum_o);
+                loss -= m[s] * logq;
+                msum += m[s];
+            } else {
+                const float lq = logf(q[s]);
+                const float l1 = log1pf(-q[s]);
+                const bool live0 = lq > -100.f, live1 = l1 > -100.f;
+                loss -= m[s] * fmaxf(lq, -100.f) + (1.f - m[s]) * fmaxf(l1, -100.f);
+                float gg = 0.f;
+                if (live0) gg -= m[s] / q[s];
+                if (live1) gg += (1.f - m[s]) / (1.f - q[s]);
+                gi[s] = gg / (float)N;
+                gq += gi[s] * q[s];
+            }
+        }
+    }
+    loss = wave_sum(loss);
+    if (a.use_ce) {
+        msum = wave_sum(msum);
+    } else {
+        loss /= (float)N;
+        gq = wave_sum(gq);
+    }
+    const float scale = w * a.inv_B;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int i = lane + 64 * s;
+        if (i < N) {
+            const float dl = a.use_ce ? (q[s] * msum - m[s]) : q[s] * (gi[s] - gq);
+            a.dlogits[(size_t)b * a.ld + i] = dl * scale;
+        }
+    }
+    if (lane == 0) {
+        a.per_loss[b] = loss;
+        a.priority[b] = fabsf(loss) + 1e-4f;
+        atomicAdd(&a.metrics[MET_VALUE_LOSS], loss * scale);
+    }
+}
+
+D4PG_API int d4pg_critic_loss(const D4pgLossArgs* a, hipStream_t stream) {
+    if (a->N < 2 || a->N > 64 * MAX_ATOM_SLOTS || a->ld < a->N || a->B < 1) return -1;
+    const dim3 grid((a->B + 3) / 4), block(256);
+    switch ((a->N + 63) / 64) {
+        case 1: hipLaunchKernelGGL(d4pg_critic_loss_kernel<1>, grid, block, 0, stream, *a); break;
+        case 2: hipLaunchKernelGGL(d4pg_critic_loss_kernel<2>, grid, block, 0, stream, *a); break;
+        case 3: hipLaunchKernelGGL(d4pg_critic_loss_kernel<3>, grid, block, 0, stream, *a); break;
+        default: hipLaunchKernelGGL(d4pg_critic_loss_kernel<4>, grid, block, 0, stream, *a); break;
+    }
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+struct D4pgActorLossArgs {
+    const float* logits;   // [B, ld] online critic logits at (s, pi(s))
+    float* dlogits;        // [B, ld]
+    float* q_out;          // [B] expected Q (may be null)
+    float* metrics;
+    int B, N, ld;
+    float v_min, v_max;
+    float inv_B;
+};
+
+template <int SLOTS>
+__global__ __launch_bounds__(256) void d4pg_actor_loss_kernel(const D4pgActorLossArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= a.B) return;
+    const int N = a.N;
+    const float dz = (a.v_max - a.v_min) / (float)(N - 1);
+    float e[SLOTS];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int j = lane + 64 * s;
+        e[s] = j < N ? a.logits[(size_t)b * a.ld + j] : -INFINITY;
+        mx = fmaxf(mx, e[s]);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f, qz = 0.f;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int j = lane + 64 * s;
+        e[s] = j < N ? __expf(e[s] - mx) : 0.f;
+        sum += e[s];
+        qz += e[s] * (a.v_min + dz * (float)j);
+    }
+    sum = wave_sum(sum);
+    qz = wave_sum(qz);
+    const float inv = 1.f / sum;
+    const float qv = qz * inv;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int j = lane + 64 * s;
+        if (j < N) {
+            const float z = a.v_min + dz * (float)j;
+            a.dlogits[(size_t)b * a.ld + j] = -a.inv_B * (e[s] * inv) * (z - qv);
+        }
+    }
+    if (lane == 0) {
+        if (a.q_out) a.q_out[b] = qv;
+        atomicAdd(&a.metrics[MET_POLICY_LOSS], -qv * a.inv_B);
+    }
+}
+
+D4PG_API int d4pg_actor_loss(const D4pgActorLossArgs* a, hipStream_t stream) {
+    if (a->N < 2 || a->N > 64 * MAX_ATOM_SLOTS || a->ld < a->N || a->B < 1) return -1;
+    const dim3 grid((a->B + 3) / 4), block(256);
+    switch ((a->N + 63) / 64) {
+        case 1: hipLaunchKernelGGL(d4pg_actor_loss_kernel<1>, grid, block, 0, stream, *a); break;
+        case 2: hipLaunchKernelGGL(d4pg_actor_loss_kernel<2>, grid, block, 0, stream, *a); break;
+        case 3: hipLaunchKernelGGL(d4pg_actor_loss_kernel<3>, grid, block, 0, stream, *a); break;
+        default: hipLaunchKernelGGL(d4pg_actor_loss_kernel<4>, grid, block, 0, stream, *a); break;
+    }
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Scalar-critic (D3PG / DDPG) losses.
+struct D3pgLossArgs {
+    const float* q_t;       // [B, ldq] target critic output at (s', pi'(s'))
+    const float* q;         // [B, ldq] online critic output at (s, a)
+    const float* reward;
+    const float* done;
+    const float* gamma;
+    const float* weights;   // may be null
+    float* dq;              // [B, ldq] gradient of the critic loss w.r.t. q
+    float* per_loss;        // [B]
+    float* priority;        // [B]
+    float* metrics;
+    int B, ldq;
+    float fixed_gamma;      // < 0: per-sample
+    float min_value, max_value;
+    float inv_B;
+};
+
+__global__ __launch_bounds__(256) void d3pg_critic_loss_kernel(const D3pgLossArgs a) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    float contrib = 0.f;
+    if (b < a.B) {
+        const float g = a.fixed_gamma >= 0.f ? a.fixed_gamma : a.gamma[b];
+        float y = a.reward[b] + (1.f - a.done[b]) * g * a.q_t[(size_t)b * a.ldq];
+        y = fminf(a.max_value, fmaxf(a.min_value, y));
+        const float diff = a.q[(size_t)b * a.ldq] - y;
+        const float w = a.weights ? a.weights[b] : 1.f;
+        const float l = diff * diff;
+        a.per_loss[b] = l;
+        a.priority[b] = fabsf(l) + 1e-4f;
+        a.dq[(size_t)b * a.ldq] = 2.f * diff * w * a.inv_B;
+        contrib = l * w * a.inv_B;
+    }
+    contrib = wave_sum(contrib);
+    if ((threadIdx.x & 63) == 0 && contrib != 0.f) atomicAdd(&a.metrics[MET_VALUE_LOSS], contrib);
+}
+
+D4PG_API int d3pg_critic_loss(const D3pgLossArgs* a, hipStream_t stream) {
+    if (a->B < 1 || a->ldq < 1) return -1;
+    hipLaunchKernelGGL(d3pg_critic_loss_kernel, dim3((a->B + 255) / 256), dim3(256), 0, stream, *a);
+    return (int)hipGetLastError();
+}
+
+// Actor loss of the scalar critic: L = -mean Q(s, pi(s))  =>  dQ = -1/B, metric -= Q/B.
+struct D3pgActorLossArgs {
+    const float* q;   // [B, ldq]
+    float* dq;        // [B, ldq]
+    float* metrics;
+    int B, ldq;
+    float inv_B;
+};
+
+__global__ __launch_bounds__(256) void d3pg_actor_loss_kernel(const D3pgActorLossArgs a) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    float contrib = 0.f;
+    if (b < a.B) {
+        a.dq[(size_t)b * a.ldq] = -a.inv_B;
+        contrib = -a.q[(size_t)b * a.ldq] * a.inv_B;
+    }
+    contrib = wave_sum(contrib);
+    if ((threadIdx.x & 63) == 0 && contrib != 0.f) atomicAdd(&a.metrics[MET_POLICY_LOSS], contrib);
+}
+
+D4PG_API int d3pg_actor_loss(const D3pgActorLossArgs* a, hipStream_t stream) {
+    if (a->B < 1 || a->ldq < 1) return -1;
+    hipLaunchKernelGGL(d3pg_actor_loss_kernel, dim3((a->B + 255) / 256), dim3(256), 0, stream, *a);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,112 @@
+// Multi-tensor optimiser kernels over the flat parameter buffer (gfx950).
+//
+//  adam_polyak_kernel : one launch applies Adam to a contiguous parameter range
+//                       AND the Polyak average of the matching target range:
+//                          m <- b1 m + (1-b1) g ; v <- b2 v + (1-b2) g^2
+//                          p <- p - (lr/bc1) m / (sqrt(v)/sqrt(bc2) + eps)
+//                          t <- (1-tau) t + tau p
+//                       (torch.optim.Adam default arithmetic; reference
+//                       models/d4pg/d4pg.py:55-56,115-117,126-138 runs ~60 tiny
+//                       launches for the same work).  float4 vectorised.
+//  polyak_kernel      : stand-alone soft update (used by tests / D2H-free target sync).
+//  tick_kernel        : advances the device step counter and bias corrections when the
+//                       update is driven without the replay-sampling kernel.
+#include "common.h"
+
+struct AdamPolyakArgs {
+    float* p;          // online parameters   [n]
+    const float* g;    // gradients           [n]
+    float* m;          // first moment        [n]
+    float* v;          // second moment       [n]
+    float* t;          // target parameters   [n] (may be null: no Polyak)
+    DevState* st;      // device state: bc1 / bc2 of the update in flight
+    float* metrics;    // metric accumulator; the finishing launch counts the update (may be null)
+    long long n;       // multiple of 4
+    float lr, beta1, beta2, eps, tau;
+    float gscale;      // gradient pre-scale (1/world_size after a sum all-reduce)
+    int finish_step;   // 1: this is the last kernel of the update -> publish step_done
+    int pad_;
+};
+
+__global__ __launch_bounds__(256) void adam_polyak_kernel(const AdamPolyakArgs a) {
+    const float bc1 = a.st->bc1, bc2 = a.st->bc2;
+    const float step_size = a.lr / bc1;
+    const float inv_sqrt_bc2 = 1.f / sqrtf(bc2);
+    const long long n4 = a.n >> 2;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        f32x4 p = reinterpret_cast<f32x4*>(a.p)[i];
+        f32x4 g = reinterpret_cast<const f32x4*>(a.g)[i];
+        f32x4 m = reinterpret_cast<f32x4*>(a.m)[i];
+        f32x4 v = reinterpret_cast<f32x4*>(a.v)[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gk = g[k] * a.gscale;
+            m[k] = a.beta1 * m[k] + (1.f - a.beta1) * gk;
+            v[k] = a.beta2 * v[k] + (1.f - a.beta2) * gk * gk;
+            const float denom = sqrtf(v[k]) * inv_sqrt_bc2 + a.eps;
+            p[k] = p[k] - step_size * (m[k] / denom);
+        }
+        reinterpret_cast<f32x4*>(a.p)[i] = p;
+        reinterpret_cast<f32x4*>(a.m)[i] = m;
+        reinterpret_cast<f32x4*>(a.v)[i] = v;
+        if (a.t != nullptr) {
+            f32x4 t = reinterpret_cast<f32x4*>(a.t)[i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[k] = (1.f - a.tau) * t[k] + a.tau * p[k];
+            reinterpret_cast<f32x4*>(a.t)[i] = t;
+        }
+    }
+    // step_done is read only by the first kernel of the next update
+    if (a.finish_step && blockIdx.x == 0 && threadIdx.x == 0) {
+        a.st->step_done = a.st->step_cur;
+        if (a.metrics != nullptr) a.metrics[MET_COUNT] += 1.f;
+    }
+}
+
+D4PG_API int d4pg_adam_polyak(const AdamPolyakArgs* a, hipStream_t stream) {
+    if (a->n < 4 || (a->n & 3)) return -1;
+    if (((uintptr_t)a->p | (uintptr_t)a->g | (uintptr_t)a->m | (uintptr_t)a->v | (uintptr_t)a->t) & 15) return -2;
+    const long long n4 = a->n >> 2;
+    int blocks = (int)((n4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(adam_polyak_kernel, dim3(blocks), dim3(256), 0, stream, *a);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void polyak_kernel(float* __restrict__ t, const float* __restrict__ p,
+                                                     long long n4, float tau) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        f32x4 tv = reinterpret_cast<f32x4*>(t)[i];
+        const f32x4 pv = reinterpret_cast<const f32x4*>(p)[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tv[k] = (1.f - tau) * tv[k] + tau * pv[k];
+        reinterpret_cast<f32x4*>(t)[i] = tv;
+    }
+}
+
+D4PG_API int d4pg_polyak(float* target, const float* online, long long n, float tau, hipStream_t stream) {
+    if (n < 4 || (n & 3) || (((uintptr_t)target | (uintptr_t)online) & 15)) return -1;
+    const long long n4 = n >> 2;
+    int blocks = (int)((n4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(polyak_kernel, dim3(blocks), dim3(256), 0, stream, target, online, n4, tau);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// The tick itself (devstate_tick) lives in common.h so the sampling kernel can inline it.
+__global__ void tick_kernel(DevState* st, float beta1, float beta2, float per_b0, float per_b1,
+                            long long total_steps) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) devstate_tick(st, beta1, beta2, per_b0, per_b1, total_steps);
+}
+
+D4PG_API int d4pg_tick(DevState* st, float beta1, float beta2, float per_b0, float per_b1, long long total_steps,
+                       hipStream_t stream) {
+    hipLaunchKernelGGL(tick_kernel, dim3(1), dim3(64), 0, stream, st, beta1, beta2, per_b0, per_b1, total_steps);
+    return (int)hipGetLastError();
+}
+
+D4PG_API int d4pg_devstate_size() { return (int)sizeof(DevState); }

@@ -1,0 +1,296 @@
+// HBM-resident replay buffer and prioritised-sampling tree (gfx950).
+//
+// Storage: array of rows, row = [state S | action A | reward | done | gamma^k | next_state S]
+// padded to a multiple of 4 floats, so a sampled transition is ONE contiguous
+// row read and a batch gather is a row-gather (no host, no pickling; the
+// reference builds each batch with a Python loop over 256 tuples,
+// models/d4pg/replay_buffer.py:41-53).
+//
+// Prioritised sampling (models/d4pg/replay_buffer.py:89-209,
+// models/d4pg/segment_tree.py) keeps the same maths — proportional, stratified,
+// p_i = priority^alpha, w_i = (P(i) n)^-beta / max_w — but the binary
+// sum-tree (21 dependent levels for 1M items) is replaced by a fan-out-64 tree:
+// one 64-lane wave scans a whole node per step, so a descent or an update is
+// 3-4 dependent memory round trips.  Internal sums are fp64 and every parent is
+// RECOMPUTED from its 64 children on update (never incrementally adjusted), so
+// there is no drift and duplicate indices in one batch are idempotent.
+// A parallel min-tree yields p_min for max_w.  Since max_w = (p_min/total*n)^-beta
+// the weight reduces to w_i = (p_min / p_i)^beta.
+#include "common.h"
+
+constexpr int MAXL = 6;
+
+struct TreeDesc {
+    float* leaf;            // [n[0]] priority^alpha, 0 for empty slots
+    double* sum[MAXL + 1];  // sum[l], l = 1..L : [n[l]] fp64 sums of 64 children
+    float* mn[MAXL + 1];    // mn[l],  l = 1..L : [n[l]] min over non-empty leaves below (+inf if none)
+    long long n[MAXL + 1];  // entries per level, each padded to a multiple of 64; n[L] <= 64
+    int L;                  // top level index (0: the leaves themselves fit one node)
+    int pad_;
+};
+
+struct ReplayDesc {
+    float* rows;            // [capacity, row_ld]
+    long long capacity;
+    int S, A, row_ld;
+    int pad_;
+};
+
+__device__ __forceinline__ double tree_load_sum(const TreeDesc& t, int level, long long idx) {
+    if (idx >= t.n[level]) return 0.0;
+    return level == 0 ? (double)t.leaf[idx] : t.sum[level][idx];
+}
+__device__ __forceinline__ float tree_load_min(const TreeDesc& t, int level, long long idx) {
+    if (idx >= t.n[level]) return INFINITY;
+    if (level == 0) {
+        const float v = t.leaf[idx];
+        return v > 0.f ? v : INFINITY;
+    }
+    return t.mn[level][idx];
+}
+
+__device__ __forceinline__ double wave_scan_incl_d(double v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double u = __shfl_up(v, o, 64);
+        if (lane >= o) v += u;
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// Insert a staged chunk of rows at the ring cursor.
+struct InsertArgs {
+    ReplayDesc rp;
+    const float* staged;     // [n, row_ld]
+    long long head;          // ring cursor before this chunk (host-tracked)
+    long long new_size;      // valid rows after this chunk
+    long long new_head;
+    int n;
+    int write_tree_inputs;   // 1: emit slot indices + initial priorities for the tree update
+    long long* slot_out;     // [n]
+    float* prio_out;         // [n]  (= running max priority, models/d4pg/replay_buffer.py:121-122)
+    DevState* st;
+};
+
+__global__ __launch_bounds__(256) void replay_insert_kernel(const InsertArgs a) {
+    const int ld4 = a.rp.row_ld >> 2;
+    const long long total = (long long)a.n * ld4;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const long long row = i / ld4;
+        const int c = (int)(i - row * ld4);
+        long long slot = a.head + row;
+        if (slot >= a.rp.capacity) slot -= a.rp.capacity;
+        reinterpret_cast<f32x4*>(a.rp.rows + slot * a.rp.row_ld)[c] =
+            reinterpret_cast<const f32x4*>(a.staged + row * a.rp.row_ld)[c];
+        if (c == 0 && a.write_tree_inputs) {
+            a.slot_out[row] = slot;
+            a.prio_out[row] = a.st->max_priority;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        a.st->replay_size = a.new_size;
+        a.st->replay_head = a.new_head;
+        a.st->inserted_total += a.n;
+    }
+}
+
+D4PG_API int d4pg_replay_insert(const InsertArgs* a, hipStream_t stream) {
+    if (a->n < 1 || a->n > a->rp.capacity || (a->rp.row_ld & 3)) return -1;
+    if (a->head < 0 || a->head >= a->rp.capacity) return -2;
+    const long long total = (long long)a->n * (a->rp.row_ld >> 2);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(replay_insert_kernel, dim3(blocks), dim3(256), 0, stream, *a);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Tree update: leaf[idx[i]] = priority[i]^alpha, then recompute every touched
+// ancestor level by level.  One workgroup (16 waves); __syncthreads() between
+// levels orders the global writes of one level before the reads of the next.
+struct TreeUpdateArgs {
+    TreeDesc t;
+    const long long* idx;   // [n]
+    const float* prio;      // [n] raw priorities
+    DevState* st;
+    int n;
+    float alpha;
+};
+
+__global__ __launch_bounds__(1024) void tree_update_kernel(const TreeUpdateArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float local_max = 0.f;
+    for (int i = tid; i < a.n; i += 1024) {
+        float p = a.prio[i];
+        if (!(p > 0.f) || p > 3.0e38f) p = 1e-4f;   // NaN / inf / non-positive never enter the tree
+        a.t.leaf[a.idx[i]] = powf(p, a.alpha);
+        local_max = fmaxf(local_max, p);
+    }
+    local_max = wave_max(local_max);
+    // positive floats order like their bit patterns
+    if (lane == 0 && local_max > 0.f)
+        atomicMax(reinterpret_cast<unsigned int*>(&a.st->max_priority), __float_as_uint(local_max));
+    __syncthreads();
+    for (int l = 1; l <= a.t.L; ++l) {
+        for (int i = wave; i < a.n; i += 16) {
+            const long long g = a.idx[i] >> (6 * l);
+            if (i > 0 && (a.idx[i - 1] >> (6 * l)) == g) continue;   // adjacent duplicate parent
+            const long long c = g * 64 + lane;
+            const double s = wave_sum_d(tree_load_sum(a.t, l - 1, c));
+            const float m = wave_min(tree_load_min(a.t, l - 1, c));
+            if (lane == 0) {
+                a.t.sum[l][g] = s;
+                a.t.mn[l][g] = m;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+D4PG_API int d4pg_tree_update(const TreeUpdateArgs* a, hipStream_t stream) {
+    if (a->n < 1 || a->t.L < 0 || a->t.L > MAXL) return -1;
+    hipLaunchKernelGGL(tree_update_kernel, dim3(1), dim3(1024), 0, stream, *a);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Sample a batch and gather it into the learner's input buffers.  One wave per
+// sample.  Also performs the per-update "tick" of the device state.
+struct SampleArgs {
+    ReplayDesc rp;
+    TreeDesc t;
+    DevState* st;
+    float* sa;        // [B, ld_x]  cols [0,S) = state, [S,S+A) = action
+    float* s_pi;      // [B, ld_x]  cols [0,S) = state          (action columns are produced by the actor)
+    float* s2_a2;     // [B, ld_x]  cols [0,S) = next state     (action columns are produced by the target actor)
+    float* reward;    // [B]
+    float* done;      // [B]
+    float* gamma;     // [B]
+    float* weights;   // [B]
+    long long* idx;   // [B]
+    int B, ld_x;
+    int prioritized;
+    int do_tick;
+    float beta1, beta2;           // Adam betas for the tick
+    float per_b0, per_b1;         // importance-exponent schedule
+    long long total_steps;
+};
+
+__global__ __launch_bounds__(256) void replay_sample_kernel(const SampleArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wave;
+    const long long step = a.st->step_done;
+    const long long size = a.st->replay_size;
+    if (b < a.B && size > 0) {
+        uint32_t rnd[4];
+        philox4x32((uint32_t)b, (uint32_t)step, (uint32_t)(step >> 32), 0x5EEDu,
+                   (uint32_t)a.st->seed, (uint32_t)(a.st->seed >> 32), rnd);
+        const double u = u01_from_bits(rnd[0], rnd[1]);
+        long long slot;
+        float w = 1.f;
+        if (!a.prioritized) {
+            slot = (long long)(u * (double)size);
+            if (slot >= size) slot = size - 1;
+        } else {
+            const TreeDesc& t = a.t;
+            // root totals from the top level
+            const double top = tree_load_sum(t, t.L, lane);
+            const double total = wave_sum_d(top);
+            const float pmin = wave_min(tree_load_min(t, t.L, lane));
+            double target = ((double)b + u) * (total / (double)a.B);
+            long long g = 0;
+            float pleaf = 0.f;
+            for (int l = t.L; l >= 0; --l) {
+                const long long c = g * 64 + lane;
+                const double v = tree_load_sum(t, l, c);
+                const double incl = wave_scan_incl_d(v, lane);
+                const unsigned long long live = __ballot(v > 0.0);
+                const unsigned long long hit = __ballot(v > 0.0 && incl > target);
+                int pick;
+                if (hit) pick = __ffsll((long long)hit) - 1;
+                else if (live) pick = 63 - __clzll((long long)live);   // rounding pushed target past the end
+                else pick = 0;
+                const double excl = __shfl(incl - v, pick, 64);
+                target -= excl;
+                if (target < 0.0) target = 0.0;
+                g = g * 64 + pick;
+                if (l == 0) pleaf = (float)__shfl(v, pick, 64);
+            }
+            slot = g < size ? g : size - 1;
+            // beta schedule evaluated locally (per_beta in DevState belongs to the tick)
+            double frac = (double)step / (double)(a.total_steps > 0 ? a.total_steps : 1);
+            frac = frac > 1.0 ? 1.0 : frac;
+            const float beta = (float)(a.per_b0 + frac * (a.per_b1 - a.per_b0));
+            w = (pleaf > 0.f && pmin < INFINITY) ? powf(pmin / pleaf, beta) : 1.f;
+        }
+        // ---- gather the row ----
+        const float* row = a.rp.rows + slot * a.rp.row_ld;
+        const int S = a.rp.S, A = a.rp.A;
+        const size_t ob = (size_t)b * a.ld_x;
+        for (int c = lane; c < S; c += 64) {
+            const float s = row[c];
+            a.sa[ob + c] = s;
+            a.s_pi[ob + c] = s;
+            a.s2_a2[ob + c] = row[S + A + 3 + c];
+        }
+        for (int c = lane; c < A; c += 64) a.sa[ob + S + c] = row[S + c];
+        if (lane == 0) {
+            a.reward[b] = row[S + A];
+            a.done[b] = row[S + A + 1];
+            a.gamma[b] = row[S + A + 2];
+            a.weights[b] = w;
+            a.idx[b] = slot;
+        }
+    }
+    if (a.do_tick && blockIdx.x == 0 && threadIdx.x == 0)
+        devstate_tick(a.st, a.beta1, a.beta2, a.per_b0, a.per_b1, a.total_steps);
+}
+
+D4PG_API int d4pg_replay_sample(const SampleArgs* a, hipStream_t stream) {
+    if (a->B < 1 || a->ld_x < a->rp.S + a->rp.A) return -1;
+    if (a->prioritized && (a->t.L < 0 || a->t.L > MAXL || a->t.n[a->t.L] > 64)) return -2;
+    hipLaunchKernelGGL(replay_sample_kernel, dim3((a->B + 3) / 4), dim3(256), 0, stream, *a);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Load an externally provided batch (host sampler / tests) into the learner's
+// input buffers with the same column layout the sampling kernel produces.
+struct ScatterBatchArgs {
+    const float* state;       // [B, S]
+    const float* action;      // [B, A]
+    const float* next_state;  // [B, S]
+    float* sa;
+    float* s_pi;
+    float* s2_a2;
+    int B, S, A, ld_x;
+};
+
+__global__ __launch_bounds__(256) void scatter_batch_kernel(const ScatterBatchArgs a) {
+    const int W = a.S + a.A;
+    const long long total = (long long)a.B * W;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / W), c = (int)(i - (long long)b * W);
+        const size_t o = (size_t)b * a.ld_x + c;
+        if (c < a.S) {
+            const float s = a.state[(size_t)b * a.S + c];
+            a.sa[o] = s;
+            a.s_pi[o] = s;
+            a.s2_a2[o] = a.next_state[(size_t)b * a.S + c];
+        } else {
+            a.sa[o] = a.action[(size_t)b * a.A + (c - a.S)];
+        }
+    }
+}
+
+D4PG_API int d4pg_scatter_batch(const ScatterBatchArgs* a, hipStream_t stream) {
+    if (a->B < 1 || a->ld_x < a->S + a->A) return -1;
+    const long long total = (long long)a->B * (a->S + a->A);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(scatter_batch_kernel, dim3(blocks), dim3(256), 0, stream, *a);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,236 @@
+"""Single-rank learner cores: the arithmetic of one update, without any IPC.
+
+A *core* owns the online and target parameter packs, the Adam moments and a
+device-side metric accumulator, and exposes ``update(batch) -> priorities``.
+Two interchangeable implementations exist:
+
+* :class:`TorchCore` (this file): eager PyTorch with autograd.  It is the
+  numerical oracle, the path of the CPU-only configuration, and the "unfused"
+  baseline on the GPU.
+* ``HipCore`` (``models/hip_core.py``): the hand-written HIP kernel pipeline
+  replayed as one HIP graph.
+
+Both keep state in the same flat layout (``models/nets.py``) so checkpoints and
+tests can move between them freely.
+
+Update order (``models/d4pg/d4pg.py:60-152``, ``models/d3pg/d3pg.py:53-112``):
+critic loss on targets from the target nets -> critic Adam -> actor loss through
+the *updated* critic -> actor Adam -> Polyak on both targets.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Dict, Optional
+
+import torch
+
+from ..config import delta_z
+from ..ops import ref
+from .nets import LearnerLayout, ParamPack
+
+
+@dataclass
+class Batch:
+    """One training batch, all tensors on the learner device.
+
+    Column meaning follows the reference's 8-element batch list
+    (``models/d4pg/replay_buffer.py:41-53``): ``gamma`` holds ``discount**k`` of
+    each n-step transition, ``weights`` the PER importance weights (ones when
+    sampling uniformly) and ``indices`` the replay slots for priority write-back.
+    """
+    state: torch.Tensor        # [B, S]
+    action: torch.Tensor       # [B, A]
+    reward: torch.Tensor       # [B]
+    next_state: torch.Tensor   # [B, S]
+    done: torch.Tensor         # [B]  (1.0 = terminal)
+    gamma: torch.Tensor        # [B]
+    weights: Optional[torch.Tensor] = None   # [B]
+    indices: Optional[torch.Tensor] = None   # [B] int64
+
+    @property
+    def size(self) -> int:
+        return self.state.shape[0]
+
+    def to(self, device) -> "Batch":
+        def mv(t):
+            return None if t is None else t.to(device, non_blocking=True)
+        return Batch(mv(self.state), mv(self.action), mv(self.reward), mv(self.next_state),
+                     mv(self.done), mv(self.gamma), mv(self.weights), mv(self.indices))
+
+
+GradSync = Callable[[torch.Tensor], None]
+
+
+class CoreBase:
+    """State shared by every core implementation."""
+
+    def __init__(self, cfg: Dict, device, seed: Optional[int] = None):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.model = cfg["model"]
+        self.distributional = self.model == "d4pg"
+        self.layout = LearnerLayout.from_config(cfg)
+        self.online = ParamPack(self.layout, device=self.device)
+        seed = cfg["random_seed"] if seed is None else seed
+        cpu_init = ParamPack(self.layout, device="cpu").init_(cfg["final_layer_init"], seed)
+        with torch.no_grad():
+            self.online.flat.copy_(cpu_init.flat)
+        # hard copy online -> target at start (d4pg.py:49-53)
+        self.target = ParamPack(self.layout, flat=self.online.flat.detach().clone())
+        self.adam_m = torch.zeros_like(self.online.flat)
+        self.adam_v = torch.zeros_like(self.online.flat)
+        self.step = 0                      # completed updates
+        self.lr_critic = cfg["critic_learning_rate"]
+        self.lr_actor = cfg["actor_learning_rate"]
+        self.tau = cfg["tau"]
+        self.betas = (cfg["adam_beta1"], cfg["adam_beta2"])
+        self.eps = cfg["adam_eps"]
+        self.v_min, self.v_max = float(cfg["v_min"]), float(cfg["v_max"])
+        self.num_atoms = cfg["num_atoms"]
+        self.fixed_gamma = float(cfg["discount_rate"]) ** int(cfg["n_step_returns"])
+        self.grad_sync: Optional[GradSync] = None
+        # [sum value_loss, sum policy_loss, count]
+        self.metrics = torch.zeros(4, dtype=torch.float32, device=self.device)
+
+    # -- metrics -----------------------------------------------------------
+    def read_metrics(self, reset: bool = True) -> Dict[str, float]:
+        """Mean losses since the last read (one device->host copy)."""
+        vals = self.metrics.detach().cpu().tolist()
+        n = max(1.0, vals[2])
+        out = {"value_loss": vals[0] / n, "policy_loss": vals[1] / n, "count": vals[2]}
+        if reset:
+            self.metrics.zero_()
+        return out
+
+    # -- checkpoint --------------------------------------------------------
+    def state_bundle(self) -> Dict:
+        """Everything needed to resume: the four networks as reference-layout
+        ``state_dict``s plus the optimiser moments and the step counter."""
+        lay = self.layout
+        a, c = lay.actor, lay.critic
+
+        def sl(t, n):
+            return t[n.base: n.base + n.numel].detach().cpu().clone()
+        return {
+            "format": "d4pg_pytorch_amd.learner.v1",
+            "model": self.model,
+            "dims": {"state_dim": lay.state_dim, "action_dim": lay.action_dim,
+                     "dense_size": lay.hidden, "critic_out": lay.critic_out},
+            "actor": self.online.actor.state_dict(),
+            "critic": self.online.critic.state_dict(),
+            "target_actor": self.target.actor.state_dict(),
+            "target_critic": self.target.critic.state_dict(),
+            "actor_optim": {"exp_avg": sl(self.adam_m, a), "exp_avg_sq": sl(self.adam_v, a)},
+            "critic_optim": {"exp_avg": sl(self.adam_m, c), "exp_avg_sq": sl(self.adam_v, c)},
+            "update_step": int(self.step),
+        }
+
+    def load_state_bundle(self, bundle: Dict) -> None:
+        lay = self.layout
+        dims = bundle["dims"]
+        want = {"state_dim": lay.state_dim, "action_dim": lay.action_dim,
+                "dense_size": lay.hidden, "critic_out": lay.critic_out}
+        if dims != want:
+            raise ValueError(f"checkpoint dims {dims} do not match config {want}")
+        self.online.actor.load_state_dict(bundle["actor"])
+        self.online.critic.load_state_dict(bundle["critic"])
+        self.target.actor.load_state_dict(bundle["target_actor"])
+        self.target.critic.load_state_dict(bundle["target_critic"])
+        with torch.no_grad():
+            for net, key in ((lay.actor, "actor_optim"), (lay.critic, "critic_optim")):
+                self.adam_m[net.base: net.base + net.numel].copy_(bundle[key]["exp_avg"].to(self.device))
+                self.adam_v[net.base: net.base + net.numel].copy_(bundle[key]["exp_avg_sq"].to(self.device))
+        self.step = int(bundle["update_step"])
+        self._after_load()
+
+    def _after_load(self) -> None:
+        pass
+
+    def gamma_of(self, batch: Batch) -> torch.Tensor:
+        if self.cfg["use_per_sample_gamma"]:
+            return batch.gamma
+        return torch.full_like(batch.gamma, self.fixed_gamma)
+
+    def update(self, batch: Batch) -> torch.Tensor:   # pragma: no cover - interface
+        raise NotImplementedError
+
+
+class TorchCore(CoreBase):
+    """Eager PyTorch implementation (oracle / CPU path / unfused baseline)."""
+
+    def __init__(self, cfg: Dict, device="cpu", seed: Optional[int] = None):
+        super().__init__(cfg, device, seed)
+        self.online.flat.requires_grad_(True)
+
+    def _views(self) -> ParamPack:
+        # fresh views so autograd sees them as functions of the flat leaf
+        return ParamPack(self.layout, flat=self.online.flat)
+
+    def _range(self, net):
+        return slice(net.base, net.base + net.numel)
+
+    def _adam(self, net, lr: float) -> None:
+        r = self._range(net)
+        g = self.online.flat.grad[r]
+        if self.grad_sync is not None:
+            self.grad_sync(g)
+        with torch.no_grad():
+            ref.adam_step_(self.online.flat[r], g, self.adam_m[r], self.adam_v[r], self.step + 1,
+                           lr, self.betas[0], self.betas[1], self.eps)
+
+    def update(self, batch: Batch) -> torch.Tensor:
+        cfg, lay = self.cfg, self.layout
+        g = self.gamma_of(batch)
+        w = batch.weights
+        # ---------------- critic ----------------
+        with torch.no_grad():
+            a2 = self.target.actor.forward(batch.next_state, "tanh")
+            out2 = self.target.critic.forward(torch.cat([batch.next_state, a2], 1), "none")
+            if self.distributional:
+                tgt = ref.l2_project(torch.softmax(out2, 1), batch.reward, batch.done, g,
+                                     self.v_min, self.v_max)
+            else:
+                tgt = ref.d3pg_td_target(batch.reward, batch.done, g, out2,
+                                         cfg["min_value"], cfg["max_value"])
+        pk = self._views()
+        self.online.flat.grad = None
+        out = pk.critic.forward(torch.cat([batch.state, batch.action], 1), "none")
+        if self.distributional:
+            value_loss, per, prio = ref.d4pg_critic_loss(out, tgt, w, cfg["critic_loss"])
+        else:
+            per = (out - tgt).pow(2).reshape(-1)          # MSELoss(reduction='none') (d3pg.py:72-74)
+            prio = per.detach().abs() + 1e-4
+            value_loss = (per if w is None else per * w).mean()
+        value_loss.backward()
+        self._adam(lay.critic, self.lr_critic)
+        # ---------------- actor (through the updated critic) ----------------
+        pk = self._views()
+        self.online.flat.grad = None
+        pi = pk.actor.forward(batch.state, "tanh")
+        qout = pk.critic.forward(torch.cat([batch.state, pi], 1), "none")
+        if self.distributional:
+            q = ref.expected_q(qout, self.v_min, self.v_max)
+        else:
+            q = qout.reshape(-1)
+        policy_loss = -q.mean()
+        policy_loss.backward()
+        self._adam(lay.actor, self.lr_actor)
+        self.online.flat.grad = None
+        # ---------------- targets ----------------
+        with torch.no_grad():
+            ref.polyak_(self.target.flat, self.online.flat, self.tau)
+            self.metrics[0] += value_loss.detach()
+            self.metrics[1] += policy_loss.detach()
+            self.metrics[2] += 1.0
+        self.step += 1
+        return prio
+
+
+def build_core(cfg: Dict, device=None, seed: Optional[int] = None) -> CoreBase:
+    """Pick the implementation for ``device``: HIP kernels on a GPU, torch on the CPU."""
+    device = torch.device(device if device is not None else cfg["device"])
+    want = cfg.get("fused_learner", "auto")
+    if device.type == "cuda" and want != "torch":
+        from .hip_core import HipCore
+        return HipCore(cfg, device, seed)
+    return TorchCore(cfg, device, seed)

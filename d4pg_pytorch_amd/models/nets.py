@@ -1,0 +1,223 @@
+"""Actor / critic parameter storage.
+
+The networks are the reference's 3-layer MLPs (``models/d4pg/networks.py:6-81``,
+``models/d3pg/networks.py:6-74``):
+
+* actor  ``S -> H -> H -> A`` with ReLU, ReLU, tanh
+* critic ``S+A -> H -> H -> N`` (D4PG, logits over N atoms) or ``-> 1`` (D3PG/DDPG)
+
+but they are not ``nn.Module`` objects.  All parameters of one learner live in
+ONE flat fp32 buffer (``ParamPack.flat``) so that the optimiser, the Polyak
+update, the gradient all-reduce and the weight publication each touch a single
+contiguous range.  Every matrix is stored row-major ``[out, ld]`` with the
+leading dimension padded to a multiple of 4 floats so the HIP kernels can use
+16-byte loads; pad columns are zero and stay zero (their gradient is zero).
+
+``state_dict`` import/export uses the reference key layout
+(``linear{1,2,3}.{weight,bias}``) with unpadded, contiguous tensors.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+
+def pad4(n: int) -> int:
+    return (n + 3) // 4 * 4
+
+
+@dataclass(frozen=True)
+class LayerSlot:
+    """Location of one linear layer inside a flat buffer (units: floats)."""
+    w_off: int
+    b_off: int
+    out_dim: int
+    in_dim: int
+    ld: int            # padded leading dimension of the weight matrix
+
+    @property
+    def w_numel(self) -> int:
+        return self.out_dim * self.ld
+
+    @property
+    def b_numel(self) -> int:
+        return pad4(self.out_dim)
+
+
+@dataclass(frozen=True)
+class NetLayout:
+    """Three linear layers packed back to back, 16-byte aligned."""
+    in_dim: int
+    hidden: int
+    out_dim: int
+    base: int
+    layers: Tuple[LayerSlot, LayerSlot, LayerSlot]
+    numel: int
+
+    @staticmethod
+    def build(in_dim: int, hidden: int, out_dim: int, base: int = 0) -> "NetLayout":
+        assert base % 4 == 0
+        dims = [(hidden, in_dim), (hidden, hidden), (out_dim, hidden)]
+        off = base
+        slots: List[LayerSlot] = []
+        for out_d, in_d in dims:
+            ld = pad4(in_d)
+            w_off = off
+            off += out_d * ld
+            off = pad4(off)
+            b_off = off
+            off += pad4(out_d)
+            slots.append(LayerSlot(w_off, b_off, out_d, in_d, ld))
+        return NetLayout(in_dim, hidden, out_dim, base, tuple(slots), off - base)
+
+
+@dataclass(frozen=True)
+class LearnerLayout:
+    """``[actor | critic]`` in one flat buffer."""
+    state_dim: int
+    action_dim: int
+    hidden: int
+    critic_out: int
+    actor: NetLayout
+    critic: NetLayout
+    numel: int
+
+    @staticmethod
+    def build(state_dim: int, action_dim: int, hidden: int, critic_out: int) -> "LearnerLayout":
+        actor = NetLayout.build(state_dim, hidden, action_dim, base=0)
+        critic = NetLayout.build(state_dim + action_dim, hidden, critic_out, base=pad4(actor.numel))
+        return LearnerLayout(state_dim, action_dim, hidden, critic_out, actor, critic,
+                             critic.base + critic.numel)
+
+    @staticmethod
+    def from_config(cfg) -> "LearnerLayout":
+        out = cfg["num_atoms"] if cfg["model"] == "d4pg" else 1
+        return LearnerLayout.build(cfg["state_dim"], cfg["action_dim"], cfg["dense_size"], out)
+
+
+STATE_DICT_KEYS = ("linear1.weight", "linear1.bias", "linear2.weight", "linear2.bias",
+                   "linear3.weight", "linear3.bias")
+
+
+class NetView:
+    """Unpadded tensor views of one network inside a flat buffer."""
+
+    def __init__(self, flat: torch.Tensor, layout: NetLayout):
+        self.layout = layout
+        self.flat = flat[layout.base: layout.base + layout.numel]
+        self.weights: List[torch.Tensor] = []
+        self.biases: List[torch.Tensor] = []
+        for s in layout.layers:
+            w = flat[s.w_off: s.w_off + s.w_numel].view(s.out_dim, s.ld)[:, : s.in_dim]
+            b = flat[s.b_off: s.b_off + s.out_dim]
+            self.weights.append(w)
+            self.biases.append(b)
+
+    def tensors(self) -> List[torch.Tensor]:
+        """``[W1, b1, W2, b2, W3, b3]`` — the order of ``nn.Module.parameters()`` in the reference."""
+        out = []
+        for w, b in zip(self.weights, self.biases):
+            out += [w, b]
+        return out
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        return {k: t.detach().clone().contiguous().cpu() for k, t in zip(STATE_DICT_KEYS, self.tensors())}
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True) -> None:
+        """Accepts reference checkpoints; ``bn1.*`` entries of the reference's
+        D3PG critic (``models/d3pg/networks.py:19``, never used in its forward)
+        are ignored."""
+        extra = [k for k in sd if k not in STATE_DICT_KEYS and not k.startswith("bn1.")]
+        if strict and extra:
+            raise KeyError(f"unexpected keys in state_dict: {extra}")
+        with torch.no_grad():
+            for k, t in zip(STATE_DICT_KEYS, self.tensors()):
+                if k not in sd:
+                    raise KeyError(f"missing key '{k}' in state_dict")
+                src = torch.as_tensor(sd[k], dtype=torch.float32)
+                if tuple(src.shape) != tuple(t.shape):
+                    raise ValueError(f"{k}: shape {tuple(src.shape)} != expected {tuple(t.shape)}")
+                t.copy_(src.to(t.device))
+
+    def forward(self, x: torch.Tensor, final: str) -> torch.Tensor:
+        from ..ops import ref
+        w1, b1, w2, b2, w3, b3 = self.tensors()
+        return ref.mlp3(x, w1, b1, w2, b2, w3, b3, final)
+
+
+def init_net_(view: NetView, final_init: float, gen: Optional[torch.Generator] = None) -> None:
+    """Reference initialisation (``networks.py:23-28,59-64``): layers 1-2 use the
+    ``nn.Linear`` default (U(+-1/sqrt(fan_in)) for weight and bias), layer 3 weight
+    and bias are U(+-final_init).  Draws on the CPU for device-independent seeds."""
+    with torch.no_grad():
+        for i, (w, b) in enumerate(zip(view.weights, view.biases)):
+            bound = final_init if i == 2 else 1.0 / math.sqrt(w.shape[1])
+            w.copy_((torch.rand(w.shape, generator=gen) * 2 - 1) * bound)
+            b.copy_((torch.rand(b.shape, generator=gen) * 2 - 1) * bound)
+
+
+class ParamPack:
+    """Flat parameter buffer of a learner (actor + critic) with named views."""
+
+    def __init__(self, layout: LearnerLayout, device="cpu", flat: Optional[torch.Tensor] = None):
+        self.layout = layout
+        if flat is None:
+            flat = torch.zeros(layout.numel, dtype=torch.float32, device=device)
+        assert flat.numel() == layout.numel and flat.dtype == torch.float32
+        self.flat = flat
+        self.actor = NetView(flat, layout.actor)
+        self.critic = NetView(flat, layout.critic)
+
+    @property
+    def device(self):
+        return self.flat.device
+
+    def init_(self, final_init: float = 3e-3, seed: Optional[int] = None) -> "ParamPack":
+        gen = None
+        if seed is not None:
+            gen = torch.Generator().manual_seed(int(seed))
+        self.flat.zero_()
+        init_net_(self.actor, final_init, gen)
+        init_net_(self.critic, final_init, gen)
+        return self
+
+    def clone(self) -> "ParamPack":
+        return ParamPack(self.layout, flat=self.flat.detach().clone())
+
+    def actor_flat(self) -> torch.Tensor:
+        a = self.layout.actor
+        return self.flat[a.base: a.base + a.numel]
+
+    def critic_flat(self) -> torch.Tensor:
+        c = self.layout.critic
+        return self.flat[c.base: c.base + c.numel]
+
+
+class ActorPolicy:
+    """Stand-alone actor used by agents (``PolicyNetwork.get_action``, ``networks.py:78-81``)."""
+
+    def __init__(self, state_dim: int, action_dim: int, hidden: int, device="cpu"):
+        self.layout = NetLayout.build(state_dim, hidden, action_dim)
+        self.flat = torch.zeros(self.layout.numel, dtype=torch.float32, device=device)
+        self.view = NetView(self.flat, self.layout)
+        self.device = torch.device(device)
+
+    def load_flat(self, flat) -> None:
+        with torch.no_grad():
+            self.flat.copy_(torch.as_tensor(flat, dtype=torch.float32).to(self.flat.device))
+
+    @torch.no_grad()
+    def act(self, states) -> torch.Tensor:
+        x = torch.as_tensor(states, dtype=torch.float32, device=self.device)
+        if x.ndim == 1:
+            x = x.unsqueeze(0)
+        return self.view.forward(x, "tanh")
+
+    def state_dict(self):
+        return self.view.state_dict()
+
+    def load_state_dict(self, sd, strict=True):
+        self.view.load_state_dict(sd, strict)

@@ -1,0 +1,224 @@
+"""ctypes bindings for the hand-written gfx950 kernels in ``csrc/*.hip``.
+
+The kernels are compiled by ``hipcc --offload-arch=gfx950`` into the in-tree
+shared object ``csrc/libd4pg_hip.so`` (see ``build.py``) with a C ABI: every
+launcher takes a pointer to an argument struct plus a ``hipStream_t`` and only
+enqueues work, so a sequence of calls issued while a torch stream is being
+captured becomes one HIP graph.
+
+Importing this module never needs a GPU; calling a launcher does.  If the
+shared object is missing the loader raises (there is no silent fallback on a
+GPU box).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libd4pg_hip.so")
+
+_lib: Optional[C.CDLL] = None
+
+# ---------------------------------------------------------------------------
+# struct mirrors (field order and types must match csrc/*.hip exactly)
+# ---------------------------------------------------------------------------
+GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
+EPI_NONE, EPI_RELU, EPI_TANH, EPI_MUL_RELU_MASK, EPI_MUL_TANH_GRAD = 0, 1, 2, 3, 4
+MAX_GROUP = 6
+MAXL = 6
+
+vp = C.c_void_p
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("A", vp), ("B", vp), ("C", vp), ("bias", vp), ("aux", vp), ("colsum", vp),
+                ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+                ("lda", C.c_int), ("ldb", C.c_int), ("ldc", C.c_int), ("ldaux", C.c_int),
+                ("kind", C.c_int), ("epi", C.c_int),
+                ("tiles_m", C.c_int), ("tiles_n", C.c_int), ("tile_base", C.c_int), ("pad_", C.c_int)]
+
+
+class GemmGroup(C.Structure):
+    _fields_ = [("p", GemmDesc * MAX_GROUP), ("count", C.c_int), ("total_tiles", C.c_int)]
+
+
+class D4pgLossArgs(C.Structure):
+    _fields_ = [("logits_t", vp), ("logits", vp), ("reward", vp), ("done", vp), ("gamma", vp),
+                ("weights", vp), ("dlogits", vp), ("per_loss", vp), ("priority", vp),
+                ("proj_out", vp), ("metrics", vp),
+                ("B", C.c_int), ("N", C.c_int), ("ld", C.c_int), ("use_ce", C.c_int),
+                ("v_min", C.c_float), ("v_max", C.c_float), ("fixed_gamma", C.c_float),
+                ("inv_B", C.c_float)]
+
+
+class D4pgActorLossArgs(C.Structure):
+    _fields_ = [("logits", vp), ("dlogits", vp), ("q_out", vp), ("metrics", vp),
+                ("B", C.c_int), ("N", C.c_int), ("ld", C.c_int),
+                ("v_min", C.c_float), ("v_max", C.c_float), ("inv_B", C.c_float)]
+
+
+class D3pgLossArgs(C.Structure):
+    _fields_ = [("q_t", vp), ("q", vp), ("reward", vp), ("done", vp), ("gamma", vp), ("weights", vp),
+                ("dq", vp), ("per_loss", vp), ("priority", vp), ("metrics", vp),
+                ("B", C.c_int), ("ldq", C.c_int),
+                ("fixed_gamma", C.c_float), ("min_value", C.c_float), ("max_value", C.c_float),
+                ("inv_B", C.c_float)]
+
+
+class D3pgActorLossArgs(C.Structure):
+    _fields_ = [("q", vp), ("dq", vp), ("metrics", vp), ("B", C.c_int), ("ldq", C.c_int),
+                ("inv_B", C.c_float)]
+
+
+class AdamPolyakArgs(C.Structure):
+    _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("t", vp), ("st", vp), ("metrics", vp),
+                ("n", C.c_longlong),
+                ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("tau", C.c_float), ("gscale", C.c_float),
+                ("finish_step", C.c_int), ("pad_", C.c_int)]
+
+
+class TreeDesc(C.Structure):
+    _fields_ = [("leaf", vp), ("sum", vp * (MAXL + 1)), ("mn", vp * (MAXL + 1)),
+                ("n", C.c_longlong * (MAXL + 1)), ("L", C.c_int), ("pad_", C.c_int)]
+
+
+class ReplayDesc(C.Structure):
+    _fields_ = [("rows", vp), ("capacity", C.c_longlong),
+                ("S", C.c_int), ("A", C.c_int), ("row_ld", C.c_int), ("pad_", C.c_int)]
+
+
+class InsertArgs(C.Structure):
+    _fields_ = [("rp", ReplayDesc), ("staged", vp), ("head", C.c_longlong), ("new_size", C.c_longlong),
+                ("new_head", C.c_longlong), ("n", C.c_int), ("write_tree_inputs", C.c_int),
+                ("slot_out", vp), ("prio_out", vp), ("st", vp)]
+
+
+class TreeUpdateArgs(C.Structure):
+    _fields_ = [("t", TreeDesc), ("idx", vp), ("prio", vp), ("st", vp), ("n", C.c_int),
+                ("alpha", C.c_float)]
+
+
+class SampleArgs(C.Structure):
+    _fields_ = [("rp", ReplayDesc), ("t", TreeDesc), ("st", vp),
+                ("sa", vp), ("s_pi", vp), ("s2_a2", vp),
+                ("reward", vp), ("done", vp), ("gamma", vp), ("weights", vp), ("idx", vp),
+                ("B", C.c_int), ("ld_x", C.c_int), ("prioritized", C.c_int), ("do_tick", C.c_int),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("per_b0", C.c_float), ("per_b1", C.c_float),
+                ("total_steps", C.c_longlong)]
+
+
+class ScatterBatchArgs(C.Structure):
+    _fields_ = [("state", vp), ("action", vp), ("next_state", vp), ("sa", vp), ("s_pi", vp),
+                ("s2_a2", vp), ("B", C.c_int), ("S", C.c_int), ("A", C.c_int), ("ld_x", C.c_int)]
+
+
+class NstepArgs(C.Structure):
+    _fields_ = [("reward", vp), ("done", vp), ("trunc", vp), ("R", vp), ("gk", vp), ("nxt", vp),
+                ("d", vp), ("T", C.c_int), ("E", C.c_int), ("n", C.c_int), ("gamma", C.c_float)]
+
+
+class DevStateMirror(C.Structure):
+    """Host mirror of ``struct DevState`` (csrc/common.h) for init / read-back."""
+    _fields_ = [("step_done", C.c_longlong), ("step_cur", C.c_longlong),
+                ("bc1", C.c_float), ("bc2", C.c_float), ("per_beta", C.c_float),
+                ("max_priority", C.c_float),
+                ("replay_size", C.c_longlong), ("replay_head", C.c_longlong),
+                ("seed", C.c_ulonglong), ("inserted_total", C.c_longlong),
+                ("pad_", C.c_longlong * 2)]
+
+
+# ---------------------------------------------------------------------------
+# loader
+# ---------------------------------------------------------------------------
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def available() -> bool:
+    return os.path.exists(LIB_PATH)
+
+
+def lib() -> C.CDLL:
+    """Load ``libd4pg_hip.so`` (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryMissing(
+                f"{LIB_PATH} not found: run `python -m d4pg_pytorch_amd.build` (hipcc --offload-arch=gfx950)")
+        # make sure the HIP runtime torch ships is the one that gets bound
+        import torch  # noqa: F401
+        _lib = C.CDLL(LIB_PATH)
+        for name, argt in (
+            ("d4pg_gemm_group", [C.POINTER(GemmGroup), vp]),
+            ("d4pg_critic_loss", [C.POINTER(D4pgLossArgs), vp]),
+            ("d4pg_actor_loss", [C.POINTER(D4pgActorLossArgs), vp]),
+            ("d3pg_critic_loss", [C.POINTER(D3pgLossArgs), vp]),
+            ("d3pg_actor_loss", [C.POINTER(D3pgActorLossArgs), vp]),
+            ("d4pg_adam_polyak", [C.POINTER(AdamPolyakArgs), vp]),
+            ("d4pg_polyak", [vp, vp, C.c_longlong, C.c_float, vp]),
+            ("d4pg_tick", [vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_longlong, vp]),
+            ("d4pg_replay_insert", [C.POINTER(InsertArgs), vp]),
+            ("d4pg_tree_update", [C.POINTER(TreeUpdateArgs), vp]),
+            ("d4pg_replay_sample", [C.POINTER(SampleArgs), vp]),
+            ("d4pg_scatter_batch", [C.POINTER(ScatterBatchArgs), vp]),
+            ("d4pg_nstep", [C.POINTER(NstepArgs), vp]),
+        ):
+            fn = getattr(_lib, name)
+            fn.argtypes = argt
+            fn.restype = C.c_int
+        _lib.d4pg_devstate_size.restype = C.c_int
+        if _lib.d4pg_devstate_size() != C.sizeof(DevStateMirror):
+            raise RuntimeError("DevState layout mismatch between csrc/common.h and ops/hip.py")
+    return _lib
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what} failed with code {rc}")
+
+
+def stream_ptr(stream: Optional[torch.cuda.Stream] = None) -> int:
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return s.cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+# ---------------------------------------------------------------------------
+# GEMM helpers
+# ---------------------------------------------------------------------------
+
+def gemm_desc(kind: int, A: torch.Tensor, lda: int, B: torch.Tensor, ldb: int, Cmat: torch.Tensor, ldc: int,
+              M: int, N: int, K: int, bias: Optional[torch.Tensor] = None, epi: int = EPI_NONE,
+              aux: Optional[torch.Tensor] = None, ldaux: int = 0,
+              colsum: Optional[torch.Tensor] = None) -> GemmDesc:
+    d = GemmDesc()
+    d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), Cmat.data_ptr()
+    d.bias = ptr(bias)
+    d.aux = ptr(aux)
+    d.colsum = ptr(colsum)
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc, d.ldaux = lda, ldb, ldc, ldaux
+    d.kind, d.epi = kind, epi
+    return d
+
+
+def gemm_group(descs: Sequence[GemmDesc], stream: Optional[torch.cuda.Stream] = None) -> None:
+    assert 1 <= len(descs) <= MAX_GROUP
+    g = GemmGroup()
+    for i, d in enumerate(descs):
+        g.p[i] = d
+    g.count = len(descs)
+    _check(lib().d4pg_gemm_group(C.byref(g), stream_ptr(stream)), "d4pg_gemm_group")
+
+
+def launch(name: str, args: C.Structure, stream: Optional[torch.cuda.Stream] = None) -> None:
+    _check(getattr(lib(), name)(C.byref(args), stream_ptr(stream)), name)
