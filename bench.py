@@ -1,0 +1,180 @@
+#!/usr/bin/env python
+"""Headline benchmark: learner updates/sec on synthetic transitions.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One *step* is one complete learner update of the named configuration: on-device
+replay sampling + gather, target actor/critic forward, categorical projection,
+critic loss/backward/Adam, actor loss through the updated critic, actor
+backward/Adam, Polyak on both targets (and the priority write-back with --per).
+Nothing is skipped or cached; weights are random-init, the replay is filled
+with synthetic transitions of the environment's observation/action shape.
+
+Configurations (the ones BASELINE.json names):
+  N == 1 : LunarLanderContinuous-v2 D4PG, batch 256, n-step 5, 51 atoms, 400-wide MLPs
+  N  > 1 : Walker2d-v2 D4PG, data-parallel learners, batch 256 per rank (weak scaling),
+           gradients all-reduced over RCCL before each Adam step
+Other shapes: --env Ant-v2 --batch 4096 --model d3pg --per ...
+
+For N > 1 the driver launches this file under torch.distributed.run (one rank
+per GPU).  Rank 0 prints ONE JSON line.  ``value`` aggregates all ranks:
+N x (synchronous updates/s), i.e. batch-256 learner updates per second summed
+over the GPUs; ``sync_updates_per_sec`` is the optimiser-step rate of the job.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3000)
+    ap.add_argument("--warmup", type=int, default=300)
+    ap.add_argument("--env", default="auto")
+    ap.add_argument("--model", default="d4pg", choices=["d4pg", "d3pg", "ddpg"])
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--per", action="store_true", help="prioritised replay (HBM sum-tree) instead of uniform")
+    ap.add_argument("--replay-size", type=int, default=1_000_000)
+    ap.add_argument("--prefill", type=int, default=200_000)
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--baseline", action="store_true",
+                    help="time the unfused eager-PyTorch update (reference op sequence) instead")
+    ap.add_argument("--no-graph", action="store_true")
+    return ap.parse_args()
+
+
+def synthetic_rows(n: int, S: int, A: int, row_ld: int, gamma_n: float, device, seed: int) -> torch.Tensor:
+    g = torch.Generator(device=device).manual_seed(seed)
+    rows = torch.zeros(n, row_ld, device=device)
+    rows[:, :S] = torch.randn(n, S, device=device, generator=g)
+    rows[:, S:S + A] = torch.rand(n, A, device=device, generator=g) * 2 - 1
+    rows[:, S + A] = torch.randn(n, device=device, generator=g)
+    rows[:, S + A + 1] = (torch.rand(n, device=device, generator=g) < 0.02).float()
+    rows[:, S + A + 2] = gamma_n
+    rows[:, S + A + 3: S + A + 3 + S] = torch.randn(n, S, device=device, generator=g)
+    return rows
+
+
+def main() -> None:
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1 and args.gpus > 1:
+        # not launched by torch.distributed.run: spawn the ranks ourselves (before any GPU use)
+        import subprocess
+        port = 29500 + (os.getpid() % 2000)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
+    from d4pg_pytorch_amd.config import default_config
+    from d4pg_pytorch_amd.parallel.comm import LocalComm, TorchDistComm, attach_data_parallel
+
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    comm = TorchDistComm(device=device) if world > 1 else LocalComm()
+
+    env = args.env
+    if env == "auto":
+        env = "LunarLanderContinuous-v2" if world == 1 else "Walker2d-v2"
+    vrange = {"LunarLanderContinuous-v2": (-200.0, 200.0), "Walker2d-v2": (0.0, 5000.0),
+              "HalfCheetah-v2": (0.0, 10000.0), "BipedalWalker-v2": (-100.0, 300.0),
+              "Ant-v2": (0.0, 4000.0), "Pendulum-v0": (-1000.0, 0.0)}.get(env, (-100.0, 100.0))
+    cfg = default_config(env=env, model=args.model, batch_size=args.batch, n_step_returns=5,
+                         dense_size=400, num_atoms=51, v_min=vrange[0], v_max=vrange[1],
+                         device="cuda", replay_mem_size=args.replay_size,
+                         replay_memory_prioritized=int(args.per), use_hip_graph=not args.no_graph,
+                         compute_dtype=args.dtype, num_steps_train=max(1, args.steps + args.warmup),
+                         fused_learner="torch" if args.baseline else "auto", random_seed=2019)
+    S, A = cfg["state_dim"], cfg["action_dim"]
+    gamma_n = cfg["discount_rate"] ** cfg["n_step_returns"]
+
+    if args.baseline:
+        from d4pg_pytorch_amd.models.core import Batch, TorchCore
+        core = TorchCore(cfg, device)
+        attach_data_parallel(core, comm)
+        rows = synthetic_rows(args.prefill, S, A, 2 * S + A + 3, gamma_n, device, seed=rank + 1)
+
+        def one_step():
+            # reference-equivalent data path: uniform host-free sampling with torch ops
+            idx = torch.randint(0, rows.shape[0], (args.batch,), device=device)
+            r = rows[idx]
+            b = Batch(r[:, :S], r[:, S:S + A], r[:, S + A], r[:, S + A + 3:S + A + 3 + S], r[:, S + A + 1],
+                      r[:, S + A + 2], None, idx)
+            core.update(b)
+    else:
+        from d4pg_pytorch_amd.models.hip_core import HipCore
+        from d4pg_pytorch_amd.replay.hbm_replay import HbmReplay
+        core = HipCore(cfg, device)
+        replay = HbmReplay(cfg, device, core.dev_state)
+        core.attach_replay(replay)
+        attach_data_parallel(core, comm)
+        n_fill = min(args.prefill, args.replay_size)
+        chunk = 50_000
+        for off in range(0, n_fill, chunk):
+            n = min(chunk, n_fill - off)
+            replay.insert(synthetic_rows(n, S, A, replay.row_ld, gamma_n, device, seed=1000 * (rank + 1) + off))
+        one_step = core.update_from_replay
+
+    for _ in range(args.warmup):
+        one_step()
+    comm.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    comm.barrier()
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    dt = comm.all_reduce_max_scalar(dt)
+
+    metrics = core.read_metrics()
+    finite = all(map(lambda v: v == v and abs(v) != float("inf"), (metrics["value_loss"], metrics["policy_loss"])))
+    if rank == 0:
+        sync_ups = args.steps / dt
+        value = sync_ups * world
+        out = {
+            "metric": "learner updates/sec",
+            "value": round(value, 2),
+            "unit": "batch-%d learner updates/s (sum over ranks)" % args.batch,
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1000.0 * dt / args.steps, 5),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype if not args.baseline else "fp32",
+            "data": "synthetic transitions (random-init weights, %d-row HBM replay prefilled with %d rows)"
+                    % (args.replay_size, min(args.prefill, args.replay_size)),
+            "sync_updates_per_sec": round(sync_ups, 2),
+            "transitions_per_sec": round(sync_ups * args.batch * world, 1),
+            "losses_finite": bool(finite),
+            "value_loss": metrics["value_loss"],
+            "policy_loss": metrics["policy_loss"],
+            "implementation": "eager-torch-unfused" if args.baseline else
+                              ("hip-kernels" + ("" if args.no_graph else "+hipgraph")),
+            "config": {"model": "%s %s (S=%d, A=%d, H=400%s)" % (
+                           env, args.model.upper(), S, A, ", 51 atoms" if args.model == "d4pg" else ""),
+                       "global_batch": args.batch * world, "seq_len": 1,
+                       "n_step": 5, "replay": "per-hbm-sumtree" if args.per else "uniform-hbm",
+                       "parallelism": "dp%d" % world},
+        }
+        print(json.dumps(out), flush=True)
+    comm.close()
+
+
+if __name__ == "__main__":
+    main()

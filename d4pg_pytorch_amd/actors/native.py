@@ -115,3 +115,15 @@ class CpuActor:
         host_lib().actor_forward(np_ptr(self.flat), self.S, self.H, self.A, np_ptr(x), x.shape[0], np_ptr(out),
                                  self.action_scale)
         return out
+
+    # reference-layout (linear1/2/3) export / import for checkpoints
+    def _view(self):
+        import torch
+        from ..models.nets import NetView
+        return NetView(torch.from_numpy(self.flat), self.layout)
+
+    def state_dict(self):
+        return self._view().state_dict()
+
+    def load_state_dict(self, sd, strict: bool = True) -> None:
+        self._view().load_state_dict(sd, strict)

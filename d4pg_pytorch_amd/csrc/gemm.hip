@@ -54,38 +54,40 @@ struct GemmGroup {
 constexpr int CH = 6;   // k-units (of 8) per register chunk; two chunks are in flight
 
 template <bool KC>
-__device__ __forceinline__ f32x4 load_frag(const float* __restrict__ P, int ld, int row, bool row_ok,
+__device__ __forceinline__ f32x4 load_frag(const float* __restrict__ P, int ld, int row_c, bool ok,
                                            int k, int K) {
     // KC:  P(row, k) = P[row*ld + k]   (one 16-byte load)
     // !KC: P(row, k) = P[k*ld + row]   (four 4-byte loads, coalesced across lanes)
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    // Branch-free: every lane always loads from a clamped, in-bounds address and the
+    // out-of-range elements are zeroed with selects.  (Predicating the loads instead
+    // puts each one in its own exec-masked block and the compiler then waits for
+    // every load before issuing the next: the K loop degenerates into serial L2
+    // round trips.)
+    f32x4 v;
     if (KC) {
-        if (row_ok && k < K) {
-            v = *reinterpret_cast<const f32x4*>(P + (size_t)row * ld + k);
-            if (k + 1 >= K) v[1] = 0.f;
-            if (k + 2 >= K) v[2] = 0.f;
-            if (k + 3 >= K) v[3] = 0.f;
-        }
+        const int ks = k < K ? k : 0;
+        v = *reinterpret_cast<const f32x4*>(P + (size_t)row_c * ld + ks);
     } else {
-        if (row_ok) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-                if (k + t < K) v[t] = P[(size_t)(k + t) * ld + row];
+        for (int t = 0; t < 4; ++t) {
+            const int ks = k + t < K ? k + t : 0;
+            v[t] = P[(size_t)ks * ld + row_c];
         }
     }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v[t] = (ok && k + t < K) ? v[t] : 0.f;
     return v;
 }
 
 template <bool AKC, bool BKC>
-__device__ __forceinline__ void load_chunk(const GemmDesc& d, int m, bool m_ok, int n, bool n_ok, int h,
+__device__ __forceinline__ void load_chunk(const GemmDesc& d, int m_c, bool m_ok, int n_c, bool n_ok, int h,
                                            int u, int u1, f32x4 (&a)[CH], f32x4 (&b)[CH]) {
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
         const int uu = u + j;
-        const int k = uu * 8 + 4 * h;
-        const bool live = uu < u1;
-        a[j] = load_frag<AKC>(d.A, d.lda, m, m_ok && live, k, d.K);
-        b[j] = load_frag<BKC>(d.B, d.ldb, n, n_ok && live, k, d.K);
+        const int k = uu < u1 ? uu * 8 + 4 * h : d.K;   // k >= K: loads a dummy in-bounds element, zeroed
+        a[j] = load_frag<AKC>(d.A, d.lda, m_c, m_ok, k, d.K);
+        b[j] = load_frag<BKC>(d.B, d.ldb, n_c, n_ok, k, d.K);
     }
 }
 
@@ -106,10 +108,13 @@ __device__ __forceinline__ void mma_chunk(f32x16& acc, float& asum, int u, int u
 template <bool AKC, bool BKC>
 __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int tm, int tn, float* red, float* cs) {
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    // readfirstlane makes the wave index (and the K range derived from it) provably
+    // wave-uniform, so the K-loop bookkeeping stays in scalar registers / branches
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int m = tm * 32 + r, n = tn * 32 + r;
     const bool m_ok = m < d.M, n_ok = n < d.N;
+    const int m_c = m_ok ? m : d.M - 1, n_c = n_ok ? n : d.N - 1;   // clamped rows for the loads
 
     const int units = (d.K + 7) >> 3;
     const int per = (units + 3) >> 2;
@@ -122,11 +127,11 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int tm, int tn, flo
     float asum = 0.f;
 
     f32x4 aA[CH], bA[CH], aB[CH], bB[CH];
-    load_chunk<AKC, BKC>(d, m, m_ok, n, n_ok, h, u0, u1, aA, bA);
+    load_chunk<AKC, BKC>(d, m_c, m_ok, n_c, n_ok, h, u0, u1, aA, bA);
     for (int u = u0; u < u1; u += 2 * CH) {
-        load_chunk<AKC, BKC>(d, m, m_ok, n, n_ok, h, u + CH, u1, aB, bB);
+        load_chunk<AKC, BKC>(d, m_c, m_ok, n_c, n_ok, h, u + CH, u1, aB, bB);
         mma_chunk(acc, asum, u, u1, aA, bA);
-        load_chunk<AKC, BKC>(d, m, m_ok, n, n_ok, h, u + 2 * CH, u1, aA, bA);
+        load_chunk<AKC, BKC>(d, m_c, m_ok, n_c, n_ok, h, u + 2 * CH, u1, aA, bA);
         mma_chunk(acc, asum, u + CH, u1, aB, bB);
     }
 

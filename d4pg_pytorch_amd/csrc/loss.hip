@@ -7,6 +7,10 @@
 //                            dlogits = -(1/B) p (z - q).
 //  d3pg_critic_loss_kernel : y = clip(r + (1-d) g Q'), per-sample (Q-y)^2, priority, dQ.
 //
+// The kernels only write per-sample results; the scalar loss metrics are reduced from
+// per_loss / q_out by the optimiser kernel that finishes the update (one same-address
+// float atomic per batch row costs more than the whole kernel body).
+//
 // Math (written from the definitions, see also ops/ref.py):
 //   z_j = v_min + j dz;  beta_j = (clip(r + (1-d) g z_j) - v_min)/dz;
 //   m_i = sum_j p_j max(0, 1 - |beta_j - i|)            (dense, atomics-free projection)
@@ -98,6 +102,7 @@ __global__ __launch_bounds__(256) void d4pg_critic_loss_kernel(const D4pgLossArg
     float m[SLOTS];
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) m[s] = 0.f;
+#pragma unroll 8
     for (int j = 0; j < N; ++j) {
         const float pj = sp[j], bj = sb[j];   // LDS broadcast reads
 #pragma unroll
@@ -154,7 +159,6 @@ __global__ __launch_bounds__(256) void d4pg_critic_loss_kernel(const D4pgLossArg
     if (lane == 0) {
         a.per_loss[b] = loss;
         a.priority[b] = fabsf(loss) + 1e-4f;
-        atomicAdd(&a.metrics[MET_VALUE_LOSS], loss * scale);
     }
 }
 
@@ -174,7 +178,7 @@ D4PG_API int d4pg_critic_loss(const D4pgLossArgs* a, hipStream_t stream) {
 struct D4pgActorLossArgs {
     const float* logits;   // [B, ld] online critic logits at (s, pi(s))
     float* dlogits;        // [B, ld]
-    float* q_out;          // [B] expected Q (may be null)
+    float* q_out;          // [B] expected Q
     float* metrics;
     int B, N, ld;
     float v_min, v_max;
@@ -218,8 +222,7 @@ __global__ __launch_bounds__(256) void d4pg_actor_loss_kernel(const D4pgActorLos
         }
     }
     if (lane == 0) {
-        if (a.q_out) a.q_out[b] = qv;
-        atomicAdd(&a.metrics[MET_POLICY_LOSS], -qv * a.inv_B);
+        a.q_out[b] = qv;
     }
 }
 
@@ -269,8 +272,7 @@ __global__ __launch_bounds__(256) void d3pg_critic_loss_kernel(const D3pgLossArg
         a.dq[(size_t)b * a.ldq] = 2.f * diff * w * a.inv_B;
         contrib = l * w * a.inv_B;
     }
-    contrib = wave_sum(contrib);
-    if ((threadIdx.x & 63) == 0 && contrib != 0.f) atomicAdd(&a.metrics[MET_VALUE_LOSS], contrib);
+    (void)contrib;
 }
 
 D4PG_API int d3pg_critic_loss(const D3pgLossArgs* a, hipStream_t stream) {
@@ -283,7 +285,7 @@ D4PG_API int d3pg_critic_loss(const D3pgLossArgs* a, hipStream_t stream) {
 struct D3pgActorLossArgs {
     const float* q;   // [B, ldq]
     float* dq;        // [B, ldq]
-    float* metrics;
+    float* q_out;     // [B] copy of Q for the metric reduction
     int B, ldq;
     float inv_B;
 };
@@ -293,10 +295,9 @@ __global__ __launch_bounds__(256) void d3pg_actor_loss_kernel(const D3pgActorLos
     float contrib = 0.f;
     if (b < a.B) {
         a.dq[(size_t)b * a.ldq] = -a.inv_B;
-        contrib = -a.q[(size_t)b * a.ldq] * a.inv_B;
+        a.q_out[b] = a.q[(size_t)b * a.ldq];
     }
-    contrib = wave_sum(contrib);
-    if ((threadIdx.x & 63) == 0 && contrib != 0.f) atomicAdd(&a.metrics[MET_POLICY_LOSS], contrib);
+    (void)contrib;
 }
 
 D4PG_API int d3pg_actor_loss(const D3pgActorLossArgs* a, hipStream_t stream) {

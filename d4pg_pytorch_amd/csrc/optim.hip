@@ -20,7 +20,12 @@ struct AdamPolyakArgs {
     float* v;          // second moment       [n]
     float* t;          // target parameters   [n] (may be null: no Polyak)
     DevState* st;      // device state: bc1 / bc2 of the update in flight
-    float* metrics;    // metric accumulator; the finishing launch counts the update (may be null)
+    float* metrics;    // metric accumulator; the finishing launch reduces the losses into it (may be null)
+    const float* per_loss;   // [B] per-sample critic loss            (finishing launch only)
+    const float* weights;    // [B] importance weights or null
+    const float* q_val;      // [B] Q(s, pi(s)); policy loss = -mean
+    int B;
+    float inv_B;
     long long n;       // multiple of 4
     float lr, beta1, beta2, eps, tau;
     float gscale;      // gradient pre-scale (1/world_size after a sum all-reduce)
@@ -58,9 +63,29 @@ __global__ __launch_bounds__(256) void adam_polyak_kernel(const AdamPolyakArgs a
         }
     }
     // step_done is read only by the first kernel of the next update
-    if (a.finish_step && blockIdx.x == 0 && threadIdx.x == 0) {
-        a.st->step_done = a.st->step_cur;
-        if (a.metrics != nullptr) a.metrics[MET_COUNT] += 1.f;
+    if (a.finish_step && blockIdx.x == 0) {
+        if (a.metrics != nullptr) {
+            // block 0 folds this update's losses into the running metric sums
+            __shared__ float red[2][4];
+            float vl = 0.f, pl = 0.f;
+            for (int b = threadIdx.x; b < a.B; b += blockDim.x) {
+                vl += a.per_loss[b] * (a.weights ? a.weights[b] : 1.f);
+                pl -= a.q_val[b];
+            }
+            vl = wave_sum(vl);
+            pl = wave_sum(pl);
+            if ((threadIdx.x & 63) == 0) {
+                red[0][threadIdx.x >> 6] = vl;
+                red[1][threadIdx.x >> 6] = pl;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                a.metrics[MET_VALUE_LOSS] += (red[0][0] + red[0][1] + red[0][2] + red[0][3]) * a.inv_B;
+                a.metrics[MET_POLICY_LOSS] += (red[1][0] + red[1][1] + red[1][2] + red[1][3]) * a.inv_B;
+                a.metrics[MET_COUNT] += 1.f;
+            }
+        }
+        if (threadIdx.x == 0) a.st->step_done = a.st->step_cur;
     }
 }
 

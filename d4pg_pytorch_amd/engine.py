@@ -1,0 +1,302 @@
+"""Job orchestration: process topology, IPC wiring, supervision, teardown.
+
+``load_engine(config).train()`` is the reference's entry
+(``models/engine.py:5-10``, ``models/d4pg/engine.py:101-158``,
+``models/d3pg/engine.py:94-151``).  The roles it spawns are kept:
+
+* learner(s)            — own the networks (one per GPU when ``num_learners > 1``)
+* sampler               — owns the replay **only in the host topology**
+                          (``replay_device: host``); with ``replay_device: hbm``
+                          that role is the ingest path + sampling kernel inside the learner
+* agent 0 (exploiter)   — greedy target policy, evaluation reward, actor checkpoints
+* agents 1..n-1         — explorers (online policy + OU noise), the data producers
+
+What is new is everything between them: transitions travel through
+shared-memory rings, weights through a seq-locked broadcast slab, counters and
+the stop flag through an atomic control block (``parallel/ipc.py``), and the
+parent is a *supervisor*: it watches exit codes and heartbeats, restarts a
+crashed explorer, tears the job down if a learner or the sampler dies, and
+always unlinks the shared segments.  (The reference only ``start()``s and
+``join()``s; a crashed child leaves the others spinning forever.)
+"""
+from __future__ import annotations
+
+import multiprocessing as mp
+import os
+import queue
+import sys
+import time
+import traceback
+from datetime import datetime
+from typing import Dict, List, Optional
+
+import numpy as np
+
+from .config import beta_at, finalize_config
+from .parallel.ipc import ControlBlock, ShmRing, WeightSlab, cleanup_names
+from .utils.logger import Logger
+from .utils.misc import empty_torch_queue
+
+
+# --------------------------------------------------------------------------- workers
+def _set_threads(n: int = 1) -> None:
+    try:
+        import torch
+        torch.set_num_threads(n)
+    except Exception:
+        pass
+
+
+def learner_worker(config: Dict, ctrl_name: str, slab_name: str, ring_names: List[str], log_dir: str,
+                   rank: int, world: int, master_port: int, batch_queue=None, priority_queue=None) -> None:
+    """Learner rank ``rank`` of ``world`` (``models/d4pg/engine.py:80-83``)."""
+    import torch
+    from .models.learner import learner_class
+    from .parallel.comm import LocalComm, TorchDistComm
+    ctrl = ControlBlock.attach(ctrl_name)
+    try:
+        device = torch.device(config["device"])
+        if device.type == "cuda":
+            index = int(config["learner_devices"][rank]) if world > 1 else (device.index or 0)
+            torch.cuda.set_device(index)
+            device = torch.device("cuda", index)
+        else:
+            _set_threads(max(1, (os.cpu_count() or 2) // 2))
+        comm = LocalComm()
+        if world > 1:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(master_port), RANK=str(rank),
+                              WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+            comm = TorchDistComm(device=device, rank=rank, world=world)
+        slab = WeightSlab.attach(slab_name) if rank == 0 else None
+        learner = learner_class(config["model"])(config, ctrl, slab, log_dir, rank, comm, device)
+        if config["replay_device"] == "hbm":
+            learner.run_hbm([ShmRing.attach(n) for n in ring_names])
+        else:
+            learner.run_host(batch_queue, priority_queue)
+        comm.close()
+    except Exception:
+        traceback.print_exc()
+        ctrl.store(ControlBlock.FAILED, 1)
+        ctrl.request_stop()
+        raise
+    finally:
+        for q in (batch_queue, priority_queue):
+            if q is not None:
+                empty_torch_queue(q)
+
+
+def sampler_worker(config: Dict, ctrl_name: str, ring_names: List[str], batch_queue, priority_queue,
+                   log_dir: str) -> None:
+    """Replay owner of the host topology (``models/d4pg/engine.py:23-77``)."""
+    from .replay.host_replay import HostReplay
+    _set_threads(1)
+    ctrl = ControlBlock.attach(ctrl_name)
+    try:
+        rings = [ShmRing.attach(n) for n in ring_names]
+        replay = HostReplay(config)
+        logger = Logger(os.path.join(log_dir, "data_struct"), config.get("log_backend", "tb"))
+        batch_size = int(config["batch_size"])
+        min_rows = max(batch_size, int(config["min_replay_size"]))
+        scratch = np.empty((int(config["ingest_chunk"]), replay.row_ld), dtype=np.float32)
+        last_log = 0.0
+        while not ctrl.stop:
+            for r in rings:
+                rows = r.pop(scratch.shape[0], out=scratch)
+                if rows.shape[0]:
+                    replay.insert_rows(rows)
+            if priority_queue is not None:
+                try:
+                    while True:
+                        idx, pr = priority_queue.get_nowait()
+                        replay.update_priorities(idx, pr)
+                except queue.Empty:
+                    pass
+            if len(replay) < min_rows:
+                time.sleep(0.001)
+                continue
+            batch = replay.sample(batch_size, beta_at(config, ctrl.update_step))
+            try:
+                batch_queue.put(batch, timeout=0.1)
+            except queue.Full:
+                pass
+            now = time.time()
+            if now - last_log > 0.5:
+                last_log, step = now, ctrl.update_step
+                logger.scalar_summary("data_struct/global_episode", ctrl.global_episode, step)
+                logger.scalar_summary("data_struct/replay_queue", sum(len(r) for r in rings), step)
+                logger.scalar_summary("data_struct/batch_queue", batch_queue.qsize() if hasattr(batch_queue, "qsize") else 0, step)
+                logger.scalar_summary("data_struct/replay_buffer", len(replay), step)
+            ctrl.heartbeat(ctrl.n_workers - 1, int(now * 1000))
+        if config.get("save_buffer_on_disk"):
+            replay.dump(os.path.join(config["results_path"], "replay_buffer.pkl"))
+        logger.close()
+        print("Stop sampler worker.", flush=True)
+    except Exception:
+        traceback.print_exc()
+        ctrl.store(ControlBlock.FAILED, 1)
+        ctrl.request_stop()
+        raise
+    finally:
+        empty_torch_queue(batch_queue)
+        if priority_queue is not None:
+            empty_torch_queue(priority_queue)
+
+
+def agent_worker(config: Dict, ctrl_name: str, slab_name: str, ring_name: Optional[str], n_agent: int,
+                 agent_type: str, log_dir: str) -> None:
+    """Explorer / exploiter process (``models/d4pg/engine.py:86-94``)."""
+    from .actors.agent import Agent, make_policy
+    _set_threads(1)
+    ctrl = ControlBlock.attach(ctrl_name)
+    slab = WeightSlab.attach(slab_name)
+    ring = ShmRing.attach(ring_name) if ring_name else None
+    device = config["exploiter_device"] if agent_type == "exploitation" else config["agent_device"]
+    if str(device).startswith("cuda"):
+        import torch
+        if not torch.cuda.is_available():
+            device = "cpu"
+    policy = make_policy(config, device)
+    agent = Agent(config, policy, ctrl, n_agent=n_agent, agent_type=agent_type, log_dir=log_dir,
+                  ring=ring, slab=slab)
+    agent.run()
+
+
+# --------------------------------------------------------------------------- engine
+class Engine:
+    def __init__(self, config: Dict):
+        self.config = finalize_config(config)
+        self.experiment_dir: Optional[str] = None
+        self.exit_codes: Dict[str, int] = {}
+        self.final_update_step = 0
+        self.final_env_steps = 0
+        self.final_episodes = 0
+        self.restarts = 0
+
+    def _spawn(self, ctx, name: str, target, args) -> mp.Process:
+        p = ctx.Process(target=target, args=args, name=name, daemon=False)
+        p.start()
+        return p
+
+    def train(self) -> str:
+        cfg = self.config
+        ctx = mp.get_context("spawn")
+        stamp = datetime.now().strftime("%Y-%m-%d_%H:%M:%S")
+        exp_dir = os.path.join(cfg["results_path"], f"{cfg['env']}-{cfg['model']}-{stamp}")
+        os.makedirs(exp_dir, exist_ok=True)
+        self.experiment_dir = exp_dir
+        world = int(cfg["num_learners"]) if str(cfg["device"]).startswith("cuda") else 1
+        n_agents = int(cfg["num_agents"])
+        n_explorers_per_rank = n_agents - 1
+        total_agents = 1 + world * n_explorers_per_rank
+        host_mode = cfg["replay_device"] == "host"
+        if host_mode and world > 1:
+            raise ValueError("data-parallel learners need replay_device: hbm")
+
+        from .models.nets import NetLayout
+        from .replay.hbm_replay import row_ld
+        n_actor = NetLayout.build(cfg["state_dim"], cfg["dense_size"], cfg["action_dim"]).numel
+        ctrl = ControlBlock.create(n_workers=total_agents + 4)
+        slab = WeightSlab.create(2 * n_actor)
+        rings: List[ShmRing] = []
+        names = [ctrl.name, slab.name]
+        procs: Dict[str, mp.Process] = {}
+        specs: Dict[str, tuple] = {}
+        batch_queue = priority_queue = None
+        try:
+            rl = row_ld(cfg["state_dim"], cfg["action_dim"])
+            for _ in range(world * n_explorers_per_rank):
+                r = ShmRing.create(int(cfg["ring_capacity"]), rl)
+                rings.append(r)
+                names.append(r.name)
+            ring_names = [r.name for r in rings]
+            port = 29600 + (os.getpid() % 3000)
+            if host_mode:
+                batch_queue = ctx.Queue(maxsize=int(cfg["batch_queue_size"]))
+                priority_queue = ctx.Queue(maxsize=int(cfg["replay_queue_size"])) \
+                    if cfg["replay_memory_prioritized"] else None
+                specs["sampler"] = (sampler_worker, (cfg, ctrl.name, ring_names, batch_queue, priority_queue, exp_dir))
+            for rank in range(world):
+                mine = ring_names[rank * n_explorers_per_rank:(rank + 1) * n_explorers_per_rank]
+                specs[f"learner-{rank}"] = (learner_worker, (cfg, ctrl.name, slab.name, mine, exp_dir, rank, world,
+                                                             port, batch_queue, priority_queue))
+            specs["agent-0"] = (agent_worker, (cfg, ctrl.name, slab.name, None, 0, "exploitation", exp_dir))
+            for i in range(world * n_explorers_per_rank):
+                specs[f"agent-{i + 1}"] = (agent_worker, (cfg, ctrl.name, slab.name, ring_names[i], i + 1,
+                                                          "exploration", exp_dir))
+            # learners first: agents block on nothing, but fresh weights should exist early
+            for name, (fn, args) in specs.items():
+                procs[name] = self._spawn(ctx, name, fn, args)
+            self._supervise(ctx, procs, specs, ctrl)
+        finally:
+            ctrl.request_stop()
+            deadline = time.time() + 30.0
+            for name, p in procs.items():
+                p.join(timeout=max(0.1, deadline - time.time()))
+                if p.is_alive():
+                    print(f"[engine] terminating unresponsive process {name}", flush=True)
+                    p.terminate()
+                    p.join(timeout=5.0)
+                    if p.is_alive():
+                        p.kill()
+                self.exit_codes[name] = p.exitcode if p.exitcode is not None else -999
+            self.final_update_step = ctrl.update_step
+            self.final_env_steps = ctrl.env_steps
+            self.final_episodes = ctrl.global_episode
+            failed = ctrl.load(ControlBlock.FAILED)
+            for q in (batch_queue, priority_queue):
+                if q is not None:
+                    empty_torch_queue(q)
+            for r in rings:
+                r.close()
+            slab.close()
+            ctrl.close()
+            cleanup_names(names)
+        if failed:
+            raise RuntimeError(f"training failed; exit codes: {self.exit_codes}")
+        return exp_dir
+
+    def _supervise(self, ctx, procs: Dict[str, mp.Process], specs: Dict[str, tuple], ctrl: ControlBlock) -> None:
+        cfg = self.config
+        hb_timeout_ms = float(cfg["heartbeat_timeout_s"]) * 1000.0
+        max_restarts = 3
+        while True:
+            time.sleep(0.05)
+            if ctrl.stop:
+                return
+            for name, p in list(procs.items()):
+                if p.is_alive():
+                    continue
+                code = p.exitcode
+                critical = name.startswith("learner") or name == "sampler"
+                if critical:
+                    if code != 0:
+                        print(f"[engine] {name} died with exit code {code}: stopping the job", flush=True)
+                        ctrl.store(ControlBlock.FAILED, 1)
+                    ctrl.request_stop()
+                    return
+                if code != 0 and not ctrl.stop:
+                    if self.restarts < max_restarts:
+                        self.restarts += 1
+                        print(f"[engine] {name} crashed (exit {code}); restart {self.restarts}/{max_restarts}", flush=True)
+                        fn, args = specs[name]
+                        procs[name] = self._spawn(ctx, name, fn, args)
+                    else:
+                        print(f"[engine] {name} keeps crashing: stopping the job", flush=True)
+                        ctrl.store(ControlBlock.FAILED, 1)
+                        ctrl.request_stop()
+                        return
+            if ctrl.load(ControlBlock.LEARNER_ALIVE):
+                hb = ctrl.last_heartbeat(0)
+                if hb and time.time() * 1000.0 - hb > hb_timeout_ms:
+                    print("[engine] learner heartbeat lost: stopping the job", flush=True)
+                    ctrl.store(ControlBlock.FAILED, 1)
+                    ctrl.request_stop()
+                    return
+
+
+def load_engine(config: Dict) -> Engine:
+    """Engine for ``config['model']`` in {ddpg, d3pg, d4pg}; anything else raises
+    (the reference returns ``None`` silently, ``models/engine.py:7-10``)."""
+    print(f"Loading {config.get('model')} for {config.get('env')}.", flush=True)
+    cfg = finalize_config(config)
+    return Engine(cfg)

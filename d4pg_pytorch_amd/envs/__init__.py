@@ -1,0 +1,50 @@
+"""Environment factory (``env/utils.py:7-15`` ``create_env_wrapper``).
+
+Resolution order for ``config['env']``:
+
+1. ``synthetic_env: true``  -> shape-only :class:`SyntheticVec`
+2. built-in native dynamics -> ``Pendulum-v0/v1`` (:class:`PendulumVec`)
+3. gym / gymnasium, if installed -> :class:`GymVec` (reward /100 for Pendulum and
+   LunarLanderContinuous like ``env/pendulum.py:13-14`` and
+   ``env/lunar_lander_continous.py:12-13``; identity otherwise)
+4. native analytic stand-in of the same shape (``InvertedPendulum-v2`` -> cart-pole)
+5. shape-only synthetic environment (with a warning), so that every shipped
+   configuration can at least run its full pipeline.
+"""
+from __future__ import annotations
+
+import warnings
+
+from .base import BoxSpace, VecEnv
+from .gym_adapter import GymVec, gym_available
+from .pendulum import PendulumVec
+from .synthetic import CartPoleContinuousVec, SyntheticVec
+
+REWARD_SCALE = {"Pendulum-v0": 100.0, "Pendulum-v1": 100.0, "LunarLanderContinuous-v2": 100.0}
+
+
+def create_env_wrapper(config, num_envs=None, seed=None) -> VecEnv:
+    name = config["env"]
+    E = int(num_envs if num_envs is not None else config.get("envs_per_agent", 1))
+    S, A = config["state_dim"], config["action_dim"]
+    lo, hi = config["action_low"], config["action_high"]
+    if config.get("synthetic_env"):
+        return SyntheticVec(name, E, S, A, lo, hi, seed, episode_len=config["max_ep_length"])
+    if name in ("Pendulum-v0", "Pendulum-v1"):
+        return PendulumVec(E, seed, env_name=name)
+    if gym_available():
+        try:
+            return GymVec(name, E, S, A, lo, hi, seed, REWARD_SCALE.get(name, 1.0))
+        except Exception as exc:   # unknown id, missing simulator backend, ...
+            warnings.warn(f"gym could not create '{name}' ({exc}); using a stand-in", stacklevel=2)
+    if name == "InvertedPendulum-v2":
+        return CartPoleContinuousVec(E, seed, time_limit=config["max_ep_length"], env_name=name)
+    warnings.warn(f"no simulator for '{name}': using the shape-only synthetic environment "
+                  f"(state_dim={S}, action_dim={A})", stacklevel=2)
+    env = SyntheticVec(name, E, S, A, lo, hi, seed, episode_len=config["max_ep_length"])
+    env.reward_scale = REWARD_SCALE.get(name, 1.0)
+    return env
+
+
+__all__ = ["create_env_wrapper", "VecEnv", "BoxSpace", "PendulumVec", "SyntheticVec",
+           "CartPoleContinuousVec", "GymVec", "gym_available"]

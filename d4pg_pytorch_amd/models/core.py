@@ -67,6 +67,8 @@ class CoreBase:
     def __init__(self, cfg: Dict, device, seed: Optional[int] = None):
         self.cfg = cfg
         self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.model = cfg["model"]
         self.distributional = self.model == "d4pg"
         self.layout = LearnerLayout.from_config(cfg)

@@ -169,6 +169,8 @@ class HipCore(CoreBase):
             a.lr, a.beta1, a.beta2, a.eps, a.tau = lr, b1, b2, self.eps, self.tau
             a.gscale, a.finish_step = 1.0, finish
             a.metrics = self.metrics.data_ptr() if finish else None
+            a.per_loss, a.weights, a.q_val = self.per_loss.data_ptr(), self.weights.data_ptr(), self.q_val.data_ptr()
+            a.B, a.inv_B = self.B, 1.0 / self.B
             return a
 
         def seg_critic() -> None:
@@ -251,7 +253,7 @@ class HipCore(CoreBase):
                 H.launch("d4pg_actor_loss", aa)
             else:
                 aa = H.D3pgActorLossArgs()
-                aa.q, aa.dq, aa.metrics = self.out_q.data_ptr(), self.dout_q.data_ptr(), self.metrics.data_ptr()
+                aa.q, aa.dq, aa.q_out = self.out_q.data_ptr(), self.dout_q.data_ptr(), self.q_val.data_ptr()
                 aa.B, aa.ldq, aa.inv_B = self.B, ldn, self.inv_global_batch
                 H.launch("d3pg_actor_loss", aa)
             # dX-only critic backward down to the action columns

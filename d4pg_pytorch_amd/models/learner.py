@@ -1,0 +1,249 @@
+"""Learner process: owns the networks, drives updates, publishes weights.
+
+Process-level counterpart of the reference's ``LearnerD4PG`` / ``LearnerD3PG``
+(``models/d4pg/d4pg.py:15-171``, ``models/d3pg/d3pg.py:14-128``): construct from
+the config, ``run()`` until ``num_steps_train`` updates are done, log
+``learner/policy_loss``, ``learner/value_loss`` and the update timing, publish
+actor weights every ``weight_publish_interval`` updates, then raise the stop flag.
+
+Two data paths:
+
+* ``run_hbm``  — GPU topology.  The replay shard and its priority tree live in
+  this process on the learner's GPU; explorer rings are drained in chunks
+  through pinned staging buffers and async H2D copies; sampling, the update and
+  the priority write-back are one HIP graph (``models/hip_core.py``).
+* ``run_host`` — CPU topology.  A sampler process owns the replay and feeds
+  ready batches through a queue, as in the reference.
+
+Losses are accumulated on the device and read back every ``metrics_interval``
+updates (the reference forces two device syncs per update with ``.item()``,
+``models/d4pg/d4pg.py:150-151``).
+"""
+from __future__ import annotations
+
+import os
+import queue
+import time
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from ..parallel.comm import Comm, LocalComm, attach_data_parallel
+from ..parallel.ipc import ControlBlock, ShmRing, WeightSlab
+from ..utils.checkpoint import load_learner_bundle, save_learner_bundle
+from ..utils.logger import Logger
+from .core import Batch, build_core
+
+
+class RingIngestor:
+    """Moves transition rows from explorer rings into an HBM replay shard."""
+
+    def __init__(self, rings: List[ShmRing], replay, device, chunk: int, n_buffers: int = 3):
+        self.rings, self.replay, self.device = rings, replay, device
+        self.chunk = int(chunk)
+        self.pinned = [torch.zeros(self.chunk, replay.row_ld).pin_memory() for _ in range(n_buffers)]
+        self.staged = [torch.zeros(self.chunk, replay.row_ld, device=device) for _ in range(n_buffers)]
+        self.events = [None] * n_buffers
+        self._next = 0
+        self.rows_ingested = 0
+
+    def poll(self, max_chunks_per_ring: int = 4) -> int:
+        moved = 0
+        for ring in self.rings:
+            for _ in range(max_chunks_per_ring):
+                if len(ring) == 0:
+                    break
+                i = self._next
+                if self.events[i] is not None:
+                    self.events[i].synchronize()      # the previous H2D out of this pinned buffer is done
+                rows = ring.pop(self.chunk, out=self.pinned[i].numpy())
+                n = rows.shape[0]
+                if n == 0:
+                    break
+                self.staged[i][:n].copy_(self.pinned[i][:n], non_blocking=True)
+                self.replay.insert(self.staged[i][:n])
+                ev = torch.cuda.Event()
+                ev.record()
+                self.events[i] = ev
+                self._next = (i + 1) % len(self.pinned)
+                moved += n
+        self.rows_ingested += moved
+        return moved
+
+
+class Learner:
+    """Policy and value network update routine (process level)."""
+
+    expected_models = ("d4pg", "d3pg", "ddpg")
+
+    def __init__(self, config: Dict, ctrl: ControlBlock, slab: Optional[WeightSlab], log_dir: str = "",
+                 rank: int = 0, comm: Optional[Comm] = None, device=None):
+        if config["model"] not in self.expected_models:
+            raise ValueError(f"{type(self).__name__} cannot run model '{config['model']}'")
+        self.config, self.ctrl, self.slab, self.rank = config, ctrl, slab, rank
+        self.comm = comm or LocalComm()
+        self.device = torch.device(device if device is not None else config["device"])
+        self.log_dir = log_dir
+        self.num_train_steps = int(config["num_steps_train"])
+        self.core = build_core(config, self.device, seed=config["random_seed"])
+        if config.get("resume"):
+            self.core.load_state_bundle(load_learner_bundle(config["resume"]))
+            print(f"[learner {rank}] resumed from {config['resume']} at step {self.core.step}", flush=True)
+        attach_data_parallel(self.core, self.comm)
+        self.logger = Logger(os.path.join(log_dir, "learner"), config.get("log_backend", "tb")) \
+            if (log_dir and rank == 0) else None
+        self.timing_tag = "learner/learner_update_timing" if config["model"] == "d4pg" else "learner/update_time"
+        n_actor = self.core.layout.actor.numel
+        self._pub_host = torch.zeros(2 * n_actor)
+        if self.device.type == "cuda":
+            self._pub_host = self._pub_host.pin_memory()
+        self._n_actor = n_actor
+        self._last_metrics_t = time.time()
+        self._last_metrics_step = self.core.step
+        self._last_env_steps = 0
+
+    # ----------------------------------------------------------------- weights
+    def publish_weights(self) -> None:
+        """[online actor | target actor] -> seq-locked slab (all agents read it)."""
+        if self.slab is None or self.rank != 0:
+            return
+        n = self._n_actor
+        with torch.no_grad():
+            self._pub_host[:n].copy_(self.core.online.actor_flat().detach(), non_blocking=True)
+            self._pub_host[n:].copy_(self.core.target.actor_flat().detach(), non_blocking=True)
+        if self.device.type == "cuda":
+            torch.cuda.current_stream(self.device).synchronize()
+        self.slab.publish(self._pub_host.numpy(), self.core.step)
+
+    # ----------------------------------------------------------------- logging
+    def _log_metrics(self, extra: Optional[Dict[str, float]] = None) -> None:
+        m = self.core.read_metrics()
+        now = time.time()
+        steps = max(1, self.core.step - self._last_metrics_step)
+        dt = max(1e-9, now - self._last_metrics_t)
+        env_steps = self.ctrl.env_steps
+        if self.logger is not None and m["count"] > 0:
+            s = self.core.step
+            self.logger.scalar_summary("learner/policy_loss", m["policy_loss"], s)
+            self.logger.scalar_summary("learner/value_loss", m["value_loss"], s)
+            self.logger.scalar_summary(self.timing_tag, dt / steps, s)
+            self.logger.scalar_summary("perf/updates_per_s", steps / dt, s)
+            self.logger.scalar_summary("perf/env_steps_per_s", (env_steps - self._last_env_steps) / dt, s)
+            for k, v in (extra or {}).items():
+                self.logger.scalar_summary(k, v, s)
+        self.last_metrics = m
+        self._last_metrics_t, self._last_metrics_step, self._last_env_steps = now, self.core.step, env_steps
+
+    def _checkpoint(self, final: bool = False) -> Optional[str]:
+        if self.rank != 0 or not self.log_dir:
+            return None
+        name = "checkpoint_final.pt" if final else f"checkpoint_{self.core.step}.pt"
+        return save_learner_bundle(os.path.join(self.log_dir, "learner", name), self.core.state_bundle(), self.config)
+
+    def _after_update(self, extra_fn=None) -> None:
+        cfg, step = self.config, self.core.step
+        self.ctrl.store(ControlBlock.UPDATE_STEP, step)
+        if step % int(cfg["weight_publish_interval"]) == 0:
+            self.publish_weights()
+        if step % int(cfg["metrics_interval"]) == 0:
+            self._log_metrics(extra_fn() if extra_fn else None)
+            self.ctrl.heartbeat(0, int(time.time() * 1000))
+        if step % 1000 == 0 and self.rank == 0:
+            print("Training step ", step, flush=True)
+        ci = int(cfg.get("learner_checkpoint_interval") or 0)
+        if ci > 0 and step % ci == 0:
+            self._checkpoint()
+
+    def _throttle(self) -> bool:
+        """Optional updates-per-env-step cap.  Returns True if the learner should wait."""
+        ratio = self.config.get("updates_per_env_step")
+        if not ratio:
+            return False
+        return self.core.step >= float(ratio) * max(1, self.ctrl.env_steps)
+
+    def _finish(self) -> None:
+        self.publish_weights()
+        self._log_metrics()
+        self.ctrl.store(ControlBlock.UPDATE_STEP, self.core.step)
+        self._checkpoint(final=True)
+        self.ctrl.request_stop()
+        if self.logger is not None:
+            self.logger.close()
+        print("Exit learner.", flush=True)
+
+    # ----------------------------------------------------------------- hbm path
+    def run_hbm(self, rings: List[ShmRing]) -> None:
+        from ..replay.hbm_replay import HbmReplay
+        cfg, core, ctrl = self.config, self.core, self.ctrl
+        replay = HbmReplay(cfg, self.device, core.dev_state)
+        core.attach_replay(replay)
+        self.replay = replay
+        ingest = RingIngestor(rings, replay, self.device, cfg["ingest_chunk"])
+        min_rows = max(int(cfg["min_replay_size"]), int(cfg["batch_size"]))
+        ingest_every = 8
+        self.publish_weights()
+        ctrl.store(ControlBlock.LEARNER_ALIVE, 1)
+
+        def extra():
+            return {"data_struct/replay_buffer": float(len(replay)),
+                    "data_struct/replay_queue": float(sum(len(r) for r in rings)),
+                    "data_struct/global_episode": float(ctrl.global_episode),
+                    "data_struct/ring_dropped": float(sum(r.dropped for r in rings))}
+
+        while core.step < self.num_train_steps and not ctrl.stop:
+            if len(replay) < min_rows or self._throttle():
+                if ingest.poll() == 0:
+                    time.sleep(0.0005)
+                ctrl.heartbeat(0, int(time.time() * 1000))
+                continue
+            if core.step % ingest_every == 0:
+                ingest.poll()
+            core.update_from_replay()
+            self._after_update(extra)
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        if cfg.get("save_buffer_on_disk"):
+            replay.dump(os.path.join(cfg["results_path"], "replay_buffer.pkl"))
+        self._finish()
+
+    # ---------------------------------------------------------------- host path
+    def run_host(self, batch_queue, priority_queue=None) -> None:
+        cfg, core, ctrl = self.config, self.core, self.ctrl
+        self.publish_weights()
+        ctrl.store(ControlBlock.LEARNER_ALIVE, 1)
+        per = bool(cfg["replay_memory_prioritized"])
+        while core.step < self.num_train_steps and not ctrl.stop:
+            if self._throttle():
+                time.sleep(0.0005)
+                continue
+            try:
+                arrays = batch_queue.get(timeout=0.05)
+            except queue.Empty:
+                ctrl.heartbeat(0, int(time.time() * 1000))
+                continue
+            s, a, r, s2, d, g, w, idx = (torch.from_numpy(np.ascontiguousarray(x)) for x in arrays)
+            batch = Batch(s.float(), a.float(), r.float(), s2.float(), d.float(), g.float(),
+                          w.float() if per else None, idx.long()).to(self.device)
+            prio = core.update(batch)
+            if per and priority_queue is not None:
+                try:
+                    priority_queue.put((arrays[7], prio.detach().cpu().numpy()), timeout=1.0)
+                except queue.Full:
+                    pass
+            self._after_update()
+        self._finish()
+
+
+class LearnerD4PG(Learner):
+    """Distributional (51-atom categorical) critic learner (``models/d4pg/d4pg.py``)."""
+    expected_models = ("d4pg",)
+
+
+class LearnerD3PG(Learner):
+    """Scalar-critic learner for D3PG and DDPG (``models/d3pg/d3pg.py``)."""
+    expected_models = ("d3pg", "ddpg")
+
+
+def learner_class(model: str):
+    return LearnerD4PG if model == "d4pg" else LearnerD3PG

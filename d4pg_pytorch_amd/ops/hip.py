@@ -70,12 +70,13 @@ class D3pgLossArgs(C.Structure):
 
 
 class D3pgActorLossArgs(C.Structure):
-    _fields_ = [("q", vp), ("dq", vp), ("metrics", vp), ("B", C.c_int), ("ldq", C.c_int),
+    _fields_ = [("q", vp), ("dq", vp), ("q_out", vp), ("B", C.c_int), ("ldq", C.c_int),
                 ("inv_B", C.c_float)]
 
 
 class AdamPolyakArgs(C.Structure):
     _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("t", vp), ("st", vp), ("metrics", vp),
+                ("per_loss", vp), ("weights", vp), ("q_val", vp), ("B", C.c_int), ("inv_B", C.c_float),
                 ("n", C.c_longlong),
                 ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("tau", C.c_float), ("gscale", C.c_float),

@@ -1,0 +1,144 @@
+"""Collective communication for data-parallel learners.
+
+The reference has no collectives at all (one learner process, one device).
+This framework scales the learner as one process per GPU; the ranks exchange
+
+* the flat critic-gradient range   (all-reduce, before the critic Adam step),
+* the flat actor-gradient range    (all-reduce, before the actor Adam step),
+* the initial parameters           (broadcast from rank 0),
+* a tiny control vector            (all-reduce: stop flag / step agreement),
+
+all as single contiguous fp32 buffers (0.7-0.9 MB): on xGMI these messages are
+latency-bound, so one flat bucket per network is the right granularity.
+
+:class:`TorchDistComm` wraps ``torch.distributed`` (backend ``nccl`` == RCCL on
+ROCm, ``gloo`` on CPU).  :class:`LocalComm` is the world-size-1 no-op.
+:class:`ThreadComm` (``fake_comm.py``) is an in-process stand-in for tests.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import torch
+
+
+class Comm:
+    rank: int = 0
+    world: int = 1
+
+    def all_reduce_sum_(self, t: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError
+
+    def broadcast_(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:
+        raise NotImplementedError
+
+    def barrier(self) -> None:
+        raise NotImplementedError
+
+    def all_reduce_max_scalar(self, v: float, device="cpu") -> float:
+        raise NotImplementedError
+
+    def close(self) -> None:
+        pass
+
+
+class LocalComm(Comm):
+    def all_reduce_sum_(self, t):
+        return t
+
+    def broadcast_(self, t, src=0):
+        return t
+
+    def barrier(self):
+        pass
+
+    def all_reduce_max_scalar(self, v, device="cpu"):
+        return float(v)
+
+
+class TorchDistComm(Comm):
+    """``torch.distributed`` process group: RCCL over xGMI on GPUs, gloo on CPU."""
+
+    def __init__(self, backend: Optional[str] = None, rank: Optional[int] = None, world: Optional[int] = None,
+                 device: Optional[torch.device] = None, init_method: Optional[str] = None,
+                 timeout_s: float = 600.0):
+        import datetime
+        import torch.distributed as dist
+        self.dist = dist
+        self.device = torch.device(device) if device is not None else torch.device("cpu")
+        if backend is None:
+            backend = "nccl" if self.device.type == "cuda" else "gloo"
+        self.backend = backend
+        self._owns = False
+        if not dist.is_initialized():
+            kwargs = {}
+            if rank is not None:
+                kwargs.update(rank=rank, world_size=world)
+            if init_method is None:
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29531")
+                init_method = "env://"
+            if backend == "nccl":
+                kwargs["device_id"] = self.device
+            dist.init_process_group(backend=backend, init_method=init_method,
+                                    timeout=datetime.timedelta(seconds=timeout_s), **kwargs)
+            self._owns = True
+        self.rank = dist.get_rank()
+        self.world = dist.get_world_size()
+
+    def all_reduce_sum_(self, t):
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t
+
+    def broadcast_(self, t, src=0):
+        self.dist.broadcast(t, src=src)
+        return t
+
+    def barrier(self):
+        if self.backend == "nccl":
+            self.dist.barrier(device_ids=[self.device.index or 0])
+        else:
+            self.dist.barrier()
+
+    def all_reduce_max_scalar(self, v, device=None):
+        t = torch.tensor([float(v)], dtype=torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self._owns and self.dist.is_initialized():
+            self.dist.destroy_process_group()
+            self._owns = False
+
+
+def attach_data_parallel(core, comm: Comm) -> None:
+    """Make ``core`` a data-parallel replica: identical start, summed gradients.
+
+    * parameters, targets and Adam moments are broadcast from rank 0;
+    * each rank draws a different RNG stream for replay sampling;
+    * ``core.grad_sync`` all-reduces a flat gradient range in place such that it
+      ends up holding the gradient of the mean loss over the GLOBAL batch.  The
+      HIP core already scales its loss by 1/(world*B), so a plain sum is right;
+      the torch core averages over its local batch, so the sum is divided by world.
+    """
+    if comm.world == 1:
+        core.grad_sync = None
+        return
+    with torch.no_grad():
+        for t in (core.online.flat, core.target.flat, core.adam_m, core.adam_v):
+            comm.broadcast_(t.data if hasattr(t, "data") else t, src=0)
+    scaled_locally = hasattr(core, "set_world")
+    if scaled_locally:
+        core.set_world(comm.world)
+        st = core.read_dev_state()
+        core._write_dev_state(step=core.step, seed=(st.seed + 0x9E3779B97F4A7C15 * (comm.rank + 1)),
+                              keep_replay=True)
+        core.grad_sync = lambda g: comm.all_reduce_sum_(g)
+    else:
+        inv = 1.0 / comm.world
+
+        def sync(g: torch.Tensor) -> None:
+            comm.all_reduce_sum_(g)
+            g.mul_(inv)
+        core.grad_sync = sync

@@ -66,6 +66,8 @@ class HbmReplay:
     def __init__(self, cfg: Dict, device, dev_state: torch.Tensor, capacity: Optional[int] = None):
         self.cfg = cfg
         self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.S, self.A = int(cfg["state_dim"]), int(cfg["action_dim"])
         self.capacity = int(capacity if capacity is not None else cfg["replay_mem_size"])
         self.row_ld = row_ld(self.S, self.A)

@@ -1,0 +1,48 @@
+"""Small utilities with reference counterparts in ``utils/utils.py``."""
+from __future__ import annotations
+
+import os
+import queue as _queue
+from glob import glob
+from typing import List, Sequence
+
+import numpy as np
+
+from ..config import read_config  # noqa: F401  (reference exposes read_config from utils.utils)
+
+
+def frames_to_gif(frames: Sequence[np.ndarray], output: str, duration_ms: int = 40) -> str:
+    """Write RGB frames as an animated GIF (Pillow; imageio is not required)."""
+    from PIL import Image
+    if not frames:
+        raise ValueError("no frames to write")
+    os.makedirs(os.path.dirname(output) or ".", exist_ok=True)
+    imgs = [Image.fromarray(np.asarray(f, dtype=np.uint8)) for f in frames]
+    imgs[0].save(output, save_all=True, append_images=imgs[1:], duration=duration_ms, loop=0)
+    return output
+
+
+def make_gif(source_dir: str, output: str) -> str:
+    """GIF from ``<int>.png`` frames in a directory, ordered by the integer stem
+    (``utils/utils.py:37-52``)."""
+    from PIL import Image
+    paths = sorted(glob(os.path.join(source_dir, "*.png")),
+                   key=lambda s: int(os.path.splitext(os.path.basename(s))[0]))
+    return frames_to_gif([np.asarray(Image.open(p).convert("RGB")) for p in paths], output)
+
+
+def empty_torch_queue(q) -> int:
+    """Drain a multiprocessing queue and close it so its feeder thread cannot
+    block process exit (``utils/utils.py:69-76``).  Returns the number of items dropped."""
+    n = 0
+    while True:
+        try:
+            q.get_nowait()
+            n += 1
+        except (_queue.Empty, OSError, ValueError, EOFError):
+            break
+    try:
+        q.close()
+    except Exception:
+        pass
+    return n

@@ -163,7 +163,6 @@ def test_d4pg_critic_loss_kernel(N, vmin, vmax, kind):
     torch.testing.assert_close(prio, prio_ref, rtol=1e-4, atol=1e-6)
     torch.testing.assert_close(dl[:, :N], lo_req.grad, rtol=2e-4, atol=1e-8)
     torch.testing.assert_close(dl[:, :N], ref.d4pg_dlogits(lo, m_ref, w, kind), rtol=2e-4, atol=1e-8)
-    torch.testing.assert_close(met[0], loss.detach(), rtol=1e-4, atol=1e-6)
 
 
 def test_d4pg_critic_loss_fixed_gamma_matches_reference_scalar():
@@ -204,7 +203,6 @@ def test_d4pg_actor_loss_kernel():
     loss.backward()
     torch.testing.assert_close(q, qr.detach(), rtol=1e-5, atol=1e-3)
     torch.testing.assert_close(dl[:, :N], lg_req.grad, rtol=1e-4, atol=1e-6)
-    torch.testing.assert_close(met[1], loss.detach(), rtol=1e-5, atol=1e-3)
 
 
 def test_d3pg_loss_kernels():
@@ -227,13 +225,12 @@ def test_d3pg_loss_kernels():
     loss.backward()
     torch.testing.assert_close(per, per_ref.detach(), rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(dq[:, 0], qq.grad[:, 0], rtol=1e-5, atol=1e-7)
-    torch.testing.assert_close(met[0], loss.detach(), rtol=1e-4, atol=1e-6)
     b = H.D3pgActorLossArgs()
-    dq2, met2 = torch.zeros(B, ldq, device="cuda"), torch.zeros(4, device="cuda")
-    b.q, b.dq, b.metrics, b.B, b.ldq, b.inv_B = q.data_ptr(), dq2.data_ptr(), met2.data_ptr(), B, ldq, 1.0 / B
+    dq2, qo = torch.zeros(B, ldq, device="cuda"), torch.zeros(B, device="cuda")
+    b.q, b.dq, b.q_out, b.B, b.ldq, b.inv_B = q.data_ptr(), dq2.data_ptr(), qo.data_ptr(), B, ldq, 1.0 / B
     H.launch("d3pg_actor_loss", b)
     torch.testing.assert_close(dq2[:, 0], torch.full((B,), -1.0 / B, device="cuda"))
-    torch.testing.assert_close(met2[1], -q[:, 0].mean(), rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(qo, q[:, 0])
 
 
 # --------------------------------------------------------------------------- optimiser
@@ -250,12 +247,16 @@ def test_adam_polyak_kernel_matches_torch_adam():
     pr = torch.nn.Parameter(p0.clone())
     opt = torch.optim.Adam([pr], lr=5e-4)
     tr = t0.clone()
+    met = torch.zeros(4, device="cuda")
+    pl, wts, qv = _rand(300), torch.rand(300, device="cuda"), _rand(300)
     for step in range(1, 6):
         g = _rand(n, scale=0.1)
         H._check(H.lib().d4pg_tick(st.data_ptr(), 0.9, 0.999, 0.4, 1.0, 100, H.stream_ptr()), "tick")
         a = H.AdamPolyakArgs()
         a.p, a.g, a.m, a.v, a.t, a.st, a.metrics, a.n = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), t.data_ptr(), st.data_ptr(), None, n
         a.lr, a.beta1, a.beta2, a.eps, a.tau, a.gscale, a.finish_step = 5e-4, 0.9, 0.999, 1e-8, 0.001, 1.0, 1
+        a.metrics, a.per_loss, a.weights, a.q_val = met.data_ptr(), pl.data_ptr(), wts.data_ptr(), qv.data_ptr()
+        a.B, a.inv_B = 300, 1.0 / 300
         H.launch("d4pg_adam_polyak", a)
         pr.grad = g.clone()
         opt.step()
@@ -264,6 +265,8 @@ def test_adam_polyak_kernel_matches_torch_adam():
     torch.testing.assert_close(t, tr, rtol=1e-5, atol=1e-7)
     raw = H.DevStateMirror.from_buffer_copy(bytes(st.cpu().numpy().tobytes()))
     assert raw.step_done == 5 and raw.step_cur == 5
+    want = torch.stack([5 * (pl * wts).mean(), 5 * (-qv).mean(), torch.tensor(5.0, device="cuda")])
+    torch.testing.assert_close(met[:3], want, rtol=1e-4, atol=1e-5)
 
 
 def test_nstep_kernel():
