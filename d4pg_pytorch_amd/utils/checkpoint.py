@@ -101,10 +101,10 @@ class _LegacyUnpickler(pickle.Unpickler):
     def find_class(self, module: str, name: str):
         if module.startswith("models.") and name in ("PolicyNetwork", "ValueNetwork"):
             return _LegacyModule
-        if module == "builtins":
+        if module in ("builtins", "__builtin__"):      # protocol-2 pickles spell it the python-2 way
             if name not in _SAFE_BUILTINS:
                 raise pickle.UnpicklingError(f"refusing builtins.{name}")
-            return super().find_class(module, name)
+            return super().find_class("builtins", name)
         if module == "torch" or module.startswith(_SAFE_PREFIXES):
             return super().find_class(module, name)
         raise pickle.UnpicklingError(f"refusing to import {module}.{name} from a legacy checkpoint")

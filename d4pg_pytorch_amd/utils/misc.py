@@ -31,17 +31,26 @@ def make_gif(source_dir: str, output: str) -> str:
     return frames_to_gif([np.asarray(Image.open(p).convert("RGB")) for p in paths], output)
 
 
-def empty_torch_queue(q) -> int:
-    """Drain a multiprocessing queue and close it so its feeder thread cannot
-    block process exit (``utils/utils.py:69-76``).  Returns the number of items dropped."""
+def empty_torch_queue(q, drain: bool = False) -> int:
+    """Release a multiprocessing queue at shutdown so that no process blocks on exit
+    (the job the reference's helper of the same name does, ``utils/utils.py:69-76``).
+
+    The reference drains with ``get_nowait`` and then closes.  Draining is only safe
+    while the producer is alive: a producer that exits mid-message leaves a truncated
+    pickle in the pipe and the next ``get`` blocks forever.  So by default this only
+    detaches: ``cancel_join_thread`` (a producer must not wait at exit for its feeder
+    thread to flush into a pipe nobody reads any more; one 256-row batch already
+    exceeds the pipe buffer) and ``close``.  ``drain=True`` additionally discards what
+    is readable first.  Returns the number of items dropped."""
     n = 0
-    while True:
+    while drain:
         try:
             q.get_nowait()
             n += 1
         except (_queue.Empty, OSError, ValueError, EOFError):
             break
     try:
+        q.cancel_join_thread()
         q.close()
     except Exception:
         pass
