@@ -47,7 +47,8 @@ def parse_args():
     ap.add_argument("--per", action="store_true", help="prioritised replay (HBM sum-tree) instead of uniform")
     ap.add_argument("--replay-size", type=int, default=1_000_000)
     ap.add_argument("--prefill", type=int, default=200_000)
-    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--dtype", default="bf16", choices=["fp32", "bf16"],
+                    help="bf16: fused row-local pipeline (bf16 MFMA operands, fp32 masters/accumulate); fp32: exact f32 MFMA")
     ap.add_argument("--baseline", action="store_true",
                     help="time the unfused eager-PyTorch update (reference op sequence) instead")
     ap.add_argument("--no-graph", action="store_true")
@@ -115,9 +116,9 @@ def main() -> None:
                       r[:, S + A + 2], None, idx)
             core.update(b)
     else:
-        from d4pg_pytorch_amd.models.hip_core import HipCore
+        from d4pg_pytorch_amd.models.core import build_core
         from d4pg_pytorch_amd.replay.hbm_replay import HbmReplay
-        core = HipCore(cfg, device)
+        core = build_core(cfg, device)
         replay = HbmReplay(cfg, device, core.dev_state)
         core.attach_replay(replay)
         attach_data_parallel(core, comm)
@@ -165,7 +166,8 @@ def main() -> None:
             "value_loss": metrics["value_loss"],
             "policy_loss": metrics["policy_loss"],
             "implementation": "eager-torch-unfused" if args.baseline else
-                              ("hip-kernels" + ("" if args.no_graph else "+hipgraph")),
+                              (("hip-fused-rowlocal-bf16" if args.dtype == "bf16" else "hip-kernels-fp32-mfma")
+                               + ("" if args.no_graph else "+hipgraph")),
             "config": {"model": "%s %s (S=%d, A=%d, H=400%s)" % (
                            env, args.model.upper(), S, A, ", 51 atoms" if args.model == "d4pg" else ""),
                        "global_batch": args.batch * world, "seq_len": 1,

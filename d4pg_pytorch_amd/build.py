@@ -19,7 +19,7 @@ from typing import List
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-HIP_SOURCES = ["gemm.hip", "loss.hip", "optim.hip", "replay.hip", "nstep.hip"]
+HIP_SOURCES = ["gemm.hip", "loss.hip", "optim.hip", "replay.hip", "nstep.hip", "fused.hip"]
 HOST_SOURCES = ["host_runtime.cpp"]
 HIP_LIB = os.path.join(CSRC, "libd4pg_hip.so")
 HOST_LIB = os.path.join(CSRC, "libd4pg_host.so")
@@ -53,7 +53,8 @@ def torch_lib_dir() -> str:
 
 def build_hip(force: bool = False, verbose: bool = False) -> str:
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    deps = srcs + [os.path.join(CSRC, "common.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "loss_dev.h")]
+    deps = srcs + headers
     if not force and not _stale(HIP_LIB, deps):
         return HIP_LIB
     objdir = os.path.join(CSRC, "build")
@@ -62,7 +63,7 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     hipcc = _hipcc()
     for s in srcs:
         o = os.path.join(objdir, os.path.basename(s) + ".o")
-        if force or _stale(o, [s, os.path.join(CSRC, "common.h")]):
+        if force or _stale(o, [s] + headers):
             cmd = [hipcc, "-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)

@@ -1,0 +1,735 @@
+// Fused, row-local bf16 pipeline of the learner update (gfx950).
+//
+// Every op of the update except the weight gradients and the optimiser is local to a
+// batch row: MLP forwards, softmax, the categorical projection, the loss and the
+// activation gradients (dX) never mix rows.  So instead of one launch per layer
+// (23 dependent launches, csrc/gemm.hip) a workgroup takes a tile of 16*MT rows
+// through WHOLE chains of layers with the activations resident in LDS:
+//
+//   critic_phase : target actor(s') -> target critic(s',a') -> online critic(s,a)
+//                  -> softmax / projection / loss / dlogits -> dX through critic L3, L2
+//   actor_phase  : actor(s) -> critic(s,pi(s)) -> expected Q / dlogits
+//                  -> dX through critic L3, L2, L1(action columns) -> tanh' -> dX through actor L3, L2
+//   wgrad        : all dW / db of one network (the only reduction over the batch) as ONE
+//                  grouped launch on transposed bf16 stashes written by the phase kernels
+//
+// An update is 7 launches: sample, critic_phase, wgrad, adam, actor_phase, wgrad, adam.
+//
+// Arithmetic: bf16 MFMA (v_mfma_f32_16x16x32_bf16 in the phases, 32x32x16 in wgrad)
+// with fp32 accumulation; master weights, biases, logits, losses, gradients and Adam
+// state stay fp32.  Weights are read from bf16 "shadow" copies kept K-contiguous for
+// each use (forward: W[o][i]; backward: the transpose), refreshed by the optimiser kernel.
+// The kernel is bound by streaming those shadows from L2 (~1.4 MB per workgroup and
+// phase), not by MFMA issue, and its time is independent of the batch size until
+// B / (16*MT) exceeds the 256 CUs.
+#include "common.h"
+#include "loss_dev.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int NW = 8;          // waves per workgroup (2 per SIMD: twice the weight bytes in flight)
+constexpr int LDS_PAD = 8;     // bf16 elements appended to every LDS row (16 B: breaks the bank stride)
+
+struct LayerW {
+    const __bf16* W;     // shadow [ntiles*16][ldw], K-contiguous, zero padded
+    const float* bias;   // fp32 [N] or null
+    int ldw;             // = K32 of this layer (multiple of 32)
+    int ntiles;          // output tiles of 16 columns
+    int N;               // true number of outputs
+    int pad_;
+};
+
+// ---------------------------------------------------------------------------------------
+// One layer on a row tile held in LDS:  epi(row, col, sum_k A[row][k] * W[col][k]).
+// A : LDS bf16 [16*MT][lda] (zero padded to K32).  Wave w owns output tiles w, w+4, ...;
+// the B fragments of a tile (KS loads of 16 B per lane) are all issued before its MFMAs
+// and the next tile's are issued before this tile's MFMAs start (two register sets).
+// C/D map of 16x16x32: col = lane & 15, row = 4 * (lane >> 4) + reg.
+// ---------------------------------------------------------------------------------------
+template <int KS>
+__device__ __forceinline__ void load_b(bf16x8 (&b)[KS], const __bf16* __restrict__ wrow) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) b[ks] = *reinterpret_cast<const bf16x8*>(wrow + ks * 32);
+}
+
+template <int MT, int KS, typename F>
+__device__ __forceinline__ void mma_tile(const bf16x8 (&b)[KS], float bias, const __bf16* A, int lda, int lane, int nt,
+                                         F&& epi) {
+    const int c = lane & 15, kg = lane >> 4;
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(A + (mt * 16 + c) * lda + ks * 32 + 8 * kg);
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[ks], acc[mt], 0, 0, 0);
+        }
+    }
+    const int col = nt * 16 + c;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        f32x4 v = acc[mt];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += bias;
+        epi(mt * 16 + 4 * kg, col, v);      // 4 consecutive rows of one column
+    }
+}
+
+// The bias of a tile is fetched TOGETHER with (ahead of) that tile's B fragments: vmcnt
+// retires in issue order, so a bias load issued in the epilogue would sit behind the next
+// tile's prefetch and drain it before every epilogue.
+__device__ __forceinline__ float load_bias(const LayerW& L, int nt, int c) {
+    const int col = nt * 16 + c;
+    const int cc = col < L.N ? col : 0;
+    const float v = L.bias != nullptr ? L.bias[cc] : 0.f;
+    return col < L.N ? v : 0.f;
+}
+
+template <int MT, int KS, typename F>
+__device__ __forceinline__ void layer_ct(const __bf16* A, int lda, const LayerW& L, F&& epi) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 15, kg = lane >> 4;
+    const __bf16* wbase = L.W + (size_t)c * L.ldw + 8 * kg;
+    const size_t tstride = (size_t)16 * L.ldw;
+    bf16x8 b0[KS], b1[KS];
+    float bias0 = 0.f, bias1 = 0.f;
+    int nt = wave;
+    if (nt < L.ntiles) {
+        bias0 = load_bias(L, nt, c);
+        load_b<KS>(b0, wbase + nt * tstride);
+    }
+    for (; nt < L.ntiles; nt += 2 * NW) {
+        const bool has1 = nt + NW < L.ntiles;
+        if (has1) {
+            bias1 = load_bias(L, nt + NW, c);
+            load_b<KS>(b1, wbase + (nt + NW) * tstride);
+        }
+        mma_tile<MT, KS>(b0, bias0, A, lda, lane, nt, epi);
+        if (has1) {
+            if (nt + 2 * NW < L.ntiles) {
+                bias0 = load_bias(L, nt + 2 * NW, c);
+                load_b<KS>(b0, wbase + (nt + 2 * NW) * tstride);
+            }
+            mma_tile<MT, KS>(b1, bias1, A, lda, lane, nt + NW, epi);
+        }
+    }
+}
+
+// Runtime-K variant for the narrow layers (inputs, logits, actions): K32 <= 128 typically.
+template <int MT, typename F>
+__device__ __forceinline__ void layer_rt(const __bf16* A, int lda, const LayerW& L, F&& epi) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 15, kg = lane >> 4;
+    const int ksteps = L.ldw >> 5;
+    for (int nt = wave; nt < L.ntiles; nt += NW) {
+        const __bf16* wrow = L.W + (size_t)(nt * 16 + c) * L.ldw + 8 * kg;
+        f32x4 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int ks = 0; ks < ksteps; ++ks) {
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(wrow + ks * 32);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(A + (mt * 16 + c) * lda + ks * 32 + 8 * kg);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[mt], 0, 0, 0);
+            }
+        }
+        const int col = nt * 16 + c;
+        const float bias = (L.bias != nullptr && col < L.N) ? L.bias[col] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            f32x4 v = acc[mt];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += bias;
+            epi(mt * 16 + 4 * kg, col, v);
+        }
+    }
+}
+
+// Hidden-K layers use the compile-time variant when KSH > 0, else the runtime one.
+template <int MT, int KSH, typename F>
+__device__ __forceinline__ void layer_h(const __bf16* A, int lda, const LayerW& L, F&& epi) {
+    if constexpr (KSH > 0)
+        layer_ct<MT, KSH>(A, lda, L, epi);
+    else
+        layer_rt<MT>(A, lda, L, epi);
+}
+
+// ---- epilogue helpers -------------------------------------------------------------------
+// 4 consecutive rows (row0..row0+3) of one column -> LDS column write
+__device__ __forceinline__ void put_lds4(__bf16* buf, int ld, int row0, int col, const f32x4& v) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) buf[(row0 + r) * ld + col] = (__bf16)v[r];
+}
+// 4 consecutive batch rows of one feature -> transposed global stash XT[col][b0 .. b0+3] (8-byte store)
+__device__ __forceinline__ void put_stash4(__bf16* XT, int ldt, int col, int b0, const f32x4& v) {
+    bf16x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = (__bf16)v[r];
+    *reinterpret_cast<bf16x4*>(XT + (size_t)col * ldt + b0) = o;
+}
+
+struct PhaseDims {
+    int B;            // batch rows (multiple of 16*MT)
+    int Bp;           // leading dimension of the transposed stashes (multiple of 32, >= B)
+    int S, A, H, NO;  // state, action, hidden, critic outputs (atoms or 1)
+    int ldx_in;       // leading dimension of the fp32 input matrices (floats)
+    int ldx;          // LDS leading dim of the input tile   = pad32(S + A) + LDS_PAD
+    int ldh;          // LDS leading dim of the hidden tiles  = pad32(H) + LDS_PAD
+    int ldd;          // LDS leading dim of the dlogits tile  = pad32(NO) + LDS_PAD
+    int lda_;         // LDS leading dim of the d-action tile = pad32(A) + LDS_PAD
+    int nop;          // fp32 logits row stride in LDS        = pad16(NO)
+    int distributional;
+    int use_ce;
+    float v_min, v_max;
+    float fixed_gamma;   // < 0: per-sample gamma
+    float inv_B;         // 1 / global batch
+    float min_value, max_value;   // scalar-critic target clamp
+};
+
+struct CriticPhaseArgs {
+    PhaseDims d;
+    const float* sa;       // [B, ldx_in]  state | action
+    const float* s2;       // [B, ldx_in]  next state (action columns ignored)
+    const float* reward;
+    const float* done;
+    const float* gamma;
+    const float* weights;  // may be null
+    LayerW ta[3];          // target actor, forward
+    LayerW tc[3];          // target critic, forward
+    LayerW cf[3];          // online critic, forward
+    LayerW cb3, cb2;       // online critic, backward (transposed shadows) of layers 3 and 2
+    // transposed bf16 stashes for wgrad, each [rows16][Bp]
+    __bf16* saT;
+    __bf16* h1T;
+    __bf16* h2T;
+    __bf16* dlT;
+    __bf16* dh2T;
+    __bf16* dh1T;
+    float* per_loss;
+    float* priority;
+};
+
+__device__ __forceinline__ void zero_lds(char* smem, int bytes) {
+    for (int i = threadIdx.x * 16; i < bytes; i += blockDim.x * 16)
+        *reinterpret_cast<f32x4*>(smem + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// load `ncols` fp32 columns of M rows into a bf16 LDS tile (+ optional transposed stash)
+__device__ __forceinline__ void load_input(const float* __restrict__ src, int ld_src, int row0, int M, int ncols,
+                                           __bf16* dst, int ld_dst, __bf16* stashT, int ldt) {
+    for (int i = threadIdx.x; i < M * ncols; i += blockDim.x) {
+        const int r = i / ncols, c = i - r * ncols;
+        const float v = src[(size_t)(row0 + r) * ld_src + c];
+        dst[r * ld_dst + c] = (__bf16)v;
+        if (stashT != nullptr) stashT[(size_t)c * ldt + row0 + r] = (__bf16)v;
+    }
+}
+
+// Loss of the rows of one tile, one wave per row (SL atom slots per lane: 1 for <= 64 atoms).
+template <int SL, int M>
+__device__ __forceinline__ void critic_rows(const CriticPhaseArgs& a, int row0, int lane, int wave, const float* lg_t,
+                                            const float* lg_o, __bf16* dlg, float* sp, float* sb) {
+    const PhaseDims& d = a.d;
+    for (int r = wave; r < M; r += NW) {
+        const int b = row0 + r;
+        const float g = d.fixed_gamma >= 0.f ? d.fixed_gamma : a.gamma[b];
+        const float w = a.weights ? a.weights[b] : 1.f;
+        const float scale = w * d.inv_B;
+        if (d.distributional) {
+            float lt[SL], lo[SL], m[SL], dl[SL];
+#pragma unroll
+            for (int s = 0; s < SL; ++s) {
+                const int j = lane + 64 * s;
+                lt[s] = j < d.NO ? lg_t[r * d.nop + j] : -INFINITY;
+                lo[s] = j < d.NO ? lg_o[r * d.nop + j] : -INFINITY;
+            }
+            const float loss = d4pg_critic_row<SL>(lt, lo, a.reward[b], 1.f - a.done[b], g, d.NO, d.v_min, d.v_max,
+                                                   d.use_ce, sp + wave * 256, sb + wave * 256, lane, m, dl);
+#pragma unroll
+            for (int s = 0; s < SL; ++s) {
+                const int j = lane + 64 * s;
+                if (j < d.NO) {
+                    const __bf16 v = (__bf16)(dl[s] * scale);
+                    dlg[r * d.ldd + j] = v;
+                    a.dlT[(size_t)j * d.Bp + b] = v;
+                }
+            }
+            if (lane == 0) {
+                a.per_loss[b] = loss;
+                a.priority[b] = fabsf(loss) + 1e-4f;
+            }
+        } else if (lane == 0) {
+            float y = a.reward[b] + (1.f - a.done[b]) * g * lg_t[r * d.nop];
+            y = fminf(d.max_value, fmaxf(d.min_value, y));
+            const float diff = lg_o[r * d.nop] - y;
+            const float l = diff * diff;
+            const __bf16 v = (__bf16)(2.f * diff * scale);
+            dlg[r * d.ldd] = v;
+            a.dlT[b] = v;
+            a.per_loss[b] = l;
+            a.priority[b] = fabsf(l) + 1e-4f;
+        }
+    }
+}
+
+template <int MT, int KSH>
+__global__ __launch_bounds__(64 * NW) void critic_phase_kernel(const CriticPhaseArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int M = 16 * MT;
+    const PhaseDims& d = a.d;
+    const int row0 = blockIdx.x * M;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // ---- carve LDS (every offset a multiple of 16 bytes) ----
+    int off = 0;
+    auto carve = [&](int bytes) { char* p = smem + off; off += (bytes + 15) & ~15; return p; };
+    __bf16* xin = (__bf16*)carve(M * d.ldx * 2);    // [s | a]
+    __bf16* xin2 = (__bf16*)carve(M * d.ldx * 2);   // [s' | a']
+    __bf16* bufA = (__bf16*)carve(M * d.ldh * 2);
+    __bf16* bufB = (__bf16*)carve(M * d.ldh * 2);
+    __bf16* bufC = (__bf16*)carve(M * d.ldh * 2);   // h1 of the online critic (mask for the backward)
+    __bf16* bufD = (__bf16*)carve(M * d.ldh * 2);   // h2 of the online critic, then dh2 in place
+    __bf16* dlg = (__bf16*)carve(M * d.ldd * 2);
+    float* lg_t = (float*)carve(M * d.nop * 4);
+    float* lg_o = (float*)carve(M * d.nop * 4);
+    float* sp = (float*)carve(NW * 256 * 4);
+    float* sb = (float*)carve(NW * 256 * 4);
+    zero_lds(smem, off);
+    __syncthreads();
+    load_input(a.sa, d.ldx_in, row0, M, d.S + d.A, xin, d.ldx, a.saT, d.Bp);
+    load_input(a.s2, d.ldx_in, row0, M, d.S, xin2, d.ldx, nullptr, 0);
+    __syncthreads();
+
+    auto relu_to = [&](__bf16* buf) {
+        return [=](int r0, int col, f32x4 v) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            put_lds4(buf, d.ldh, r0, col, v);
+        };
+    };
+    // ---- target actor: s' -> a' (written into the action columns of xin2) ----
+    layer_rt<MT>(xin2, d.ldx, a.ta[0], relu_to(bufA));
+    __syncthreads();
+    layer_h<MT, KSH>(bufA, d.ldh, a.ta[1], relu_to(bufB));
+    __syncthreads();
+    layer_h<MT, KSH>(bufB, d.ldh, a.ta[2], [=](int r0, int col, f32x4 v) {
+        if (col < d.A) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+            put_lds4(xin2, d.ldx, r0, d.S + col, v);
+        }
+    });
+    __syncthreads();
+    // ---- target critic: (s', a') -> logits_t ----
+    layer_rt<MT>(xin2, d.ldx, a.tc[0], relu_to(bufA));
+    __syncthreads();
+    layer_h<MT, KSH>(bufA, d.ldh, a.tc[1], relu_to(bufB));
+    __syncthreads();
+    layer_h<MT, KSH>(bufB, d.ldh, a.tc[2], [=](int r0, int col, f32x4 v) {
+        if (col < d.nop) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lg_t[(r0 + r) * d.nop + col] = v[r];
+        }
+    });
+    // ---- online critic: (s, a) -> logits, activations stashed (transposed) for wgrad ----
+    layer_rt<MT>(xin, d.ldx, a.cf[0], [=](int r0, int col, f32x4 v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        put_lds4(bufC, d.ldh, r0, col, v);
+        put_stash4(a.h1T, d.Bp, col, row0 + r0, v);
+    });
+    __syncthreads();
+    layer_h<MT, KSH>(bufC, d.ldh, a.cf[1], [=](int r0, int col, f32x4 v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        put_lds4(bufD, d.ldh, r0, col, v);
+        put_stash4(a.h2T, d.Bp, col, row0 + r0, v);
+    });
+    __syncthreads();
+    layer_h<MT, KSH>(bufD, d.ldh, a.cf[2], [=](int r0, int col, f32x4 v) {
+        if (col < d.nop) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lg_o[(r0 + r) * d.nop + col] = v[r];
+        }
+    });
+    __syncthreads();
+    // ---- loss: one wave per row ----
+    if (d.distributional && d.NO <= 64)
+        critic_rows<1, M>(a, row0, lane, wave, lg_t, lg_o, dlg, sp, sb);
+    else
+        critic_rows<4, M>(a, row0, lane, wave, lg_t, lg_o, dlg, sp, sb);
+    __syncthreads();
+    // ---- backward through critic layers 3 and 2 (activation gradients only) ----
+    layer_rt<MT>(dlg, d.ldd, a.cb3, [=](int r0, int col, f32x4 v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (float)bufD[(r0 + r) * d.ldh + col] > 0.f ? v[r] : 0.f;
+        put_lds4(bufD, d.ldh, r0, col, v);       // in place: each element is read and written by one lane
+        put_stash4(a.dh2T, d.Bp, col, row0 + r0, v);
+    });
+    __syncthreads();
+    layer_h<MT, KSH>(bufD, d.ldh, a.cb2, [=](int r0, int col, f32x4 v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (float)bufC[(r0 + r) * d.ldh + col] > 0.f ? v[r] : 0.f;
+        put_stash4(a.dh1T, d.Bp, col, row0 + r0, v);
+    });
+}
+
+// ---------------------------------------------------------------------------------------
+struct ActorPhaseArgs {
+    PhaseDims d;
+    const float* s;        // [B, ldx_in] state (action columns ignored)
+    LayerW af[3];          // online actor, forward
+    LayerW cf[3];          // online critic (already updated), forward
+    LayerW cb3, cb2, cb1;  // critic backward: layers 3, 2 and the action columns of layer 1
+    LayerW ab3, ab2;       // actor backward: layers 3 and 2
+    __bf16* sT;            // transposed stashes [rows16][Bp]
+    __bf16* h1T;
+    __bf16* h2T;
+    __bf16* daT;
+    __bf16* dh2T;
+    __bf16* dh1T;
+    float* q_val;          // [B]
+};
+
+template <int SL, int M>
+__device__ __forceinline__ void actor_rows(const ActorPhaseArgs& a, int row0, int lane, int wave, const float* lg_o,
+                                           __bf16* dlg) {
+    const PhaseDims& d = a.d;
+    for (int r = wave; r < M; r += NW) {
+        const int b = row0 + r;
+        if (d.distributional) {
+            float e[SL], dl[SL];
+#pragma unroll
+            for (int s = 0; s < SL; ++s) {
+                const int j = lane + 64 * s;
+                e[s] = j < d.NO ? lg_o[r * d.nop + j] : -INFINITY;
+            }
+            const float qv = d4pg_actor_row<SL>(e, d.NO, d.v_min, d.v_max, lane, dl);
+#pragma unroll
+            for (int s = 0; s < SL; ++s) {
+                const int j = lane + 64 * s;
+                if (j < d.NO) dlg[r * d.ldd + j] = (__bf16)(dl[s] * d.inv_B);
+            }
+            if (lane == 0) a.q_val[b] = qv;
+        } else if (lane == 0) {
+            dlg[r * d.ldd] = (__bf16)(-d.inv_B);
+            a.q_val[b] = lg_o[r * d.nop];
+        }
+    }
+}
+
+template <int MT, int KSH>
+__global__ __launch_bounds__(64 * NW) void actor_phase_kernel(const ActorPhaseArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int M = 16 * MT;
+    const PhaseDims& d = a.d;
+    const int row0 = blockIdx.x * M;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int off = 0;
+    auto carve = [&](int bytes) { char* p = smem + off; off += (bytes + 15) & ~15; return p; };
+    __bf16* xin = (__bf16*)carve(M * d.ldx * 2);    // [s | pi(s)]
+    __bf16* bufA = (__bf16*)carve(M * d.ldh * 2);   // h1 actor
+    __bf16* bufB = (__bf16*)carve(M * d.ldh * 2);   // h2 actor, then dh2 actor in place
+    __bf16* bufC = (__bf16*)carve(M * d.ldh * 2);   // h1 critic, then dh1 critic in place
+    __bf16* bufD = (__bf16*)carve(M * d.ldh * 2);   // h2 critic, then dh2 critic in place
+    __bf16* dlg = (__bf16*)carve(M * d.ldd * 2);
+    __bf16* dab = (__bf16*)carve(M * d.lda_ * 2);
+    float* lg_o = (float*)carve(M * d.nop * 4);
+    float* pi = (float*)carve(M * 16 * ((d.A + 15) / 16) * 4);
+    const int ldpi = 16 * ((d.A + 15) / 16);
+    zero_lds(smem, off);
+    __syncthreads();
+    load_input(a.s, d.ldx_in, row0, M, d.S, xin, d.ldx, a.sT, d.Bp);
+    __syncthreads();
+    // ---- actor forward ----
+    layer_rt<MT>(xin, d.ldx, a.af[0], [=](int r0, int col, f32x4 v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        put_lds4(bufA, d.ldh, r0, col, v);
+        put_stash4(a.h1T, d.Bp, col, row0 + r0, v);
+    });
+    __syncthreads();
+    layer_h<MT, KSH>(bufA, d.ldh, a.af[1], [=](int r0, int col, f32x4 v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        put_lds4(bufB, d.ldh, r0, col, v);
+        put_stash4(a.h2T, d.Bp, col, row0 + r0, v);
+    });
+    __syncthreads();
+    layer_h<MT, KSH>(bufB, d.ldh, a.af[2], [=](int r0, int col, f32x4 v) {
+        if (col < d.A) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = tanhf(v[r]);
+                pi[(r0 + r) * ldpi + col] = v[r];
+            }
+            put_lds4(xin, d.ldx, r0, d.S + col, v);
+        }
+    });
+    __syncthreads();
+    // ---- critic forward at (s, pi(s)) ----
+    auto relu_to = [&](__bf16* buf) {
+        return [=](int r0, int col, f32x4 v) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            put_lds4(buf, d.ldh, r0, col, v);
+        };
+    };
+    layer_rt<MT>(xin, d.ldx, a.cf[0], relu_to(bufC));
+    __syncthreads();
+    layer_h<MT, KSH>(bufC, d.ldh, a.cf[1], relu_to(bufD));
+    __syncthreads();
+    layer_h<MT, KSH>(bufD, d.ldh, a.cf[2], [=](int r0, int col, f32x4 v) {
+        if (col < d.nop) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lg_o[(r0 + r) * d.nop + col] = v[r];
+        }
+    });
+    __syncthreads();
+    // ---- actor loss: -mean Q ----
+    if (d.distributional && d.NO <= 64)
+        actor_rows<1, M>(a, row0, lane, wave, lg_o, dlg);
+    else
+        actor_rows<4, M>(a, row0, lane, wave, lg_o, dlg);
+    __syncthreads();
+    // ---- critic backward (dX only) down to the action ----
+    layer_rt<MT>(dlg, d.ldd, a.cb3, [=](int r0, int col, f32x4 v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (float)bufD[(r0 + r) * d.ldh + col] > 0.f ? v[r] : 0.f;
+        put_lds4(bufD, d.ldh, r0, col, v);
+    });
+    __syncthreads();
+    layer_h<MT, KSH>(bufD, d.ldh, a.cb2, [=](int r0, int col, f32x4 v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (float)bufC[(r0 + r) * d.ldh + col] > 0.f ? v[r] : 0.f;
+        put_lds4(bufC, d.ldh, r0, col, v);
+    });
+    __syncthreads();
+    layer_h<MT, KSH>(bufC, d.ldh, a.cb1, [=](int r0, int col, f32x4 v) {
+        if (col < d.A) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float y = pi[(r0 + r) * ldpi + col];
+                v[r] *= (1.f - y * y);
+            }
+            put_lds4(dab, d.lda_, r0, col, v);
+            put_stash4(a.daT, d.Bp, col, row0 + r0, v);
+        }
+    });
+    __syncthreads();
+    // ---- actor backward ----
+    layer_rt<MT>(dab, d.lda_, a.ab3, [=](int r0, int col, f32x4 v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (float)bufB[(r0 + r) * d.ldh + col] > 0.f ? v[r] : 0.f;
+        put_lds4(bufB, d.ldh, r0, col, v);
+        put_stash4(a.dh2T, d.Bp, col, row0 + r0, v);
+    });
+    __syncthreads();
+    layer_h<MT, KSH>(bufB, d.ldh, a.ab2, [=](int r0, int col, f32x4 v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (float)bufA[(r0 + r) * d.ldh + col] > 0.f ? v[r] : 0.f;
+        put_stash4(a.dh1T, d.Bp, col, row0 + r0, v);
+    });
+}
+
+// ---------------------------------------------------------------------------------------
+// host launchers
+static int phase_lds_bytes_critic(const PhaseDims& d, int M) {
+    auto al = [](int b) { return (b + 15) & ~15; };
+    return 2 * al(M * d.ldx * 2) + 4 * al(M * d.ldh * 2) + al(M * d.ldd * 2) + 2 * al(M * d.nop * 4) +
+           2 * al(NW * 256 * 4);
+}
+static int phase_lds_bytes_actor(const PhaseDims& d, int M) {
+    auto al = [](int b) { return (b + 15) & ~15; };
+    return al(M * d.ldx * 2) + 4 * al(M * d.ldh * 2) + al(M * d.ldd * 2) + al(M * d.lda_ * 2) + al(M * d.nop * 4) +
+           al(M * 16 * ((d.A + 15) / 16) * 4);
+}
+
+static int check_dims(const PhaseDims& d, int M) {
+    if (d.B < M || d.B % M) return -1;
+    if (d.Bp < d.B || (d.Bp & 31)) return -2;
+    if ((d.ldx & 7) || (d.ldh & 7) || (d.ldd & 7) || (d.lda_ & 7)) return -3;
+    if (d.NO < 1 || d.NO > 256 || d.nop < d.NO || (d.nop & 15)) return -4;
+    if (d.ldx < d.S + d.A || d.ldx_in < d.S + d.A) return -5;
+    return 0;
+}
+static int max_k32(const PhaseDims& d) {
+    int k = d.ldh;
+    if (d.ldx > k) k = d.ldx;
+    if (d.ldd > k) k = d.ldd;
+    if (d.lda_ > k) k = d.lda_;
+    return k - LDS_PAD;
+}
+static int check_layer(const LayerW& L, int k32_max) {
+    if (L.W == nullptr || L.ntiles < 1 || (L.ldw & 31) || L.ldw < 32 || L.ldw > k32_max) return -6;
+    if (((uintptr_t)L.W) & 15) return -7;
+    return 0;
+}
+
+template <typename K, typename Args>
+static int launch_phase(K kernel, const Args& a, int grid, int lds, hipStream_t stream) {
+    if (lds > 160 * 1024) return -8;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * NW), lds, stream, a);
+    return (int)hipGetLastError();
+}
+
+#define DISPATCH_PHASE(KERNEL, LDSFN)                                                       \
+    const PhaseDims& d = a->d;                                                              \
+    const int M = 16 * mt;                                                                  \
+    if (mt != 1 && mt != 2) return -9;                                                      \
+    int rc = check_dims(d, M);                                                              \
+    if (rc) return rc;                                                                      \
+    const int lds = LDSFN(d, M);                                                            \
+    const int grid = d.B / M;                                                               \
+    const int ksh = (d.ldh - LDS_PAD) / 32;                                                 \
+    if (mt == 1) {                                                                          \
+        if (ksh == 13) return launch_phase(KERNEL<1, 13>, *a, grid, lds, stream);          \
+        if (ksh == 4) return launch_phase(KERNEL<1, 4>, *a, grid, lds, stream);            \
+        if (ksh == 8) return launch_phase(KERNEL<1, 8>, *a, grid, lds, stream);            \
+        return launch_phase(KERNEL<1, 0>, *a, grid, lds, stream);                          \
+    }                                                                                       \
+    if (ksh == 13) return launch_phase(KERNEL<2, 13>, *a, grid, lds, stream);              \
+    if (ksh == 4) return launch_phase(KERNEL<2, 4>, *a, grid, lds, stream);                \
+    if (ksh == 8) return launch_phase(KERNEL<2, 8>, *a, grid, lds, stream);                \
+    return launch_phase(KERNEL<2, 0>, *a, grid, lds, stream);
+
+D4PG_API int d4pg_critic_phase(const CriticPhaseArgs* a, int mt, hipStream_t stream) {
+    const int kmax = max_k32(a->d);
+    for (int i = 0; i < 3; ++i)
+        if (check_layer(a->ta[i], kmax) || check_layer(a->tc[i], kmax) || check_layer(a->cf[i], kmax)) return -6;
+    if (check_layer(a->cb3, kmax) || check_layer(a->cb2, kmax)) return -6;
+    DISPATCH_PHASE(critic_phase_kernel, phase_lds_bytes_critic)
+}
+
+D4PG_API int d4pg_actor_phase(const ActorPhaseArgs* a, int mt, hipStream_t stream) {
+    const int kmax = max_k32(a->d);
+    for (int i = 0; i < 3; ++i)
+        if (check_layer(a->af[i], kmax) || check_layer(a->cf[i], kmax)) return -6;
+    if (check_layer(a->cb3, kmax) || check_layer(a->cb2, kmax) || check_layer(a->cb1, kmax) ||
+        check_layer(a->ab3, kmax) || check_layer(a->ab2, kmax))
+        return -6;
+    DISPATCH_PHASE(actor_phase_kernel, phase_lds_bytes_actor)
+}
+
+D4PG_API int d4pg_phase_lds_bytes(const PhaseDims* d, int mt, int actor) {
+    return actor ? phase_lds_bytes_actor(*d, 16 * mt) : phase_lds_bytes_critic(*d, 16 * mt);
+}
+
+// ---------------------------------------------------------------------------------------
+// Weight gradients:  dW[o][i] = sum_b dYT[o][b] * XT[i][b],  db[o] = sum_b dYT[o][b]
+// Grouped (all three layers of a network in one launch), 32x32 tiles on
+// v_mfma_f32_32x32x16_bf16, four waves split the batch (K) and combine through LDS.
+// ---------------------------------------------------------------------------------------
+struct WgradDesc {
+    const __bf16* AT;   // dY^T [rowsA][Bp]
+    const __bf16* BT;   // X^T  [rowsB][Bp]
+    float* C;           // dW fp32 [M][ldc]
+    float* rowsum;      // db fp32 [M] or null
+    int M, N;           // true output rows / columns
+    int rowsA, rowsB;   // allocated (padded) rows of the stashes: loads are clamped to them
+    int ldc;
+    int tiles_m, tiles_n, tile_base;
+};
+constexpr int WG_MAX = 3;
+struct WgradGroup {
+    WgradDesc p[WG_MAX];
+    int count, total_tiles;
+    int Bp;             // K (multiple of 32)
+    int pad_;
+};
+
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradGroup g) {
+    __shared__ float red[4 * 16 * 64];
+    __shared__ float cs[4 * 32];
+    const int total = g.total_tiles;
+    const int id = blockIdx.x;
+    const int xcd = id & 7, local = id >> 3;
+    const int q = total >> 3, rem = total & 7;
+    const int tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + local;
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < WG_MAX; ++i)
+        if (i < g.count && tile >= g.p[i].tile_base) p = i;
+    const WgradDesc& d = g.p[p];
+    const int t = tile - d.tile_base;
+    const int tm = t / d.tiles_n, tn = t - tm * d.tiles_n;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int m = tm * 32 + r, n = tn * 32 + r;
+    const bool m_ok = m < d.M, n_ok = n < d.N;
+    const int m_c = m < d.rowsA ? m : d.rowsA - 1, n_c = n < d.rowsB ? n : d.rowsB - 1;
+    const __bf16* arow = d.AT + (size_t)m_c * g.Bp + 8 * h;
+    const __bf16* brow = d.BT + (size_t)n_c * g.Bp + 8 * h;
+    const int ksteps = g.Bp >> 4;              // k-steps of 16
+    const int per = (ksteps + 3) >> 2;
+    const int k0 = wave * per, k1 = min(ksteps, k0 + per);
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float asum = 0.f;
+    const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 4
+    for (int ks = k0; ks < k1; ++ks) {
+        bf16x8 av = *reinterpret_cast<const bf16x8*>(arow + ks * 16);
+        bf16x8 bv = *reinterpret_cast<const bf16x8*>(brow + ks * 16);
+        av = m_ok ? av : zero;
+        bv = n_ok ? bv : zero;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asum += (float)av[j];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[(wave * 16 + i) * 64 + lane] = acc[i];
+    if (d.rowsum != nullptr) {
+        asum += __shfl_xor(asum, 32, 64);
+        if (lane < 32) cs[wave * 32 + lane] = asum;
+    }
+    __syncthreads();
+    const int wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int reg = 4 * wv + i;
+        const float v = red[(0 * 16 + reg) * 64 + lane] + red[(1 * 16 + reg) * 64 + lane] +
+                        red[(2 * 16 + reg) * 64 + lane] + red[(3 * 16 + reg) * 64 + lane];
+        const int cm = tm * 32 + i + 8 * wv + 4 * h;
+        const int cn = tn * 32 + r;
+        if (cm < d.M && cn < d.N) d.C[(size_t)cm * d.ldc + cn] = v;
+    }
+    if (d.rowsum != nullptr && tn == 0 && threadIdx.x < 32) {
+        const int cm = tm * 32 + threadIdx.x;
+        if (cm < d.M)
+            d.rowsum[cm] = cs[threadIdx.x] + cs[32 + threadIdx.x] + cs[64 + threadIdx.x] + cs[96 + threadIdx.x];
+    }
+}
+
+D4PG_API int d4pg_wgrad(WgradGroup* g, hipStream_t stream) {
+    if (g->count < 1 || g->count > WG_MAX || g->Bp < 32 || (g->Bp & 31)) return -1;
+    int base = 0;
+    for (int i = 0; i < g->count; ++i) {
+        WgradDesc& d = g->p[i];
+        if (d.M < 1 || d.N < 1 || d.rowsA < 1 || d.rowsB < 1 || d.ldc < d.N) return -2;
+        if (d.AT == nullptr || d.BT == nullptr || d.C == nullptr) return -3;
+        if ((((uintptr_t)d.AT) | ((uintptr_t)d.BT)) & 15) return -4;
+        d.tiles_m = (d.M + 31) / 32;
+        d.tiles_n = (d.N + 31) / 32;
+        d.tile_base = base;
+        base += d.tiles_m * d.tiles_n;
+    }
+    g->total_tiles = base;
+    hipLaunchKernelGGL(wgrad_kernel, dim3(base), dim3(256), 0, stream, *g);
+    return (int)hipGetLastError();
+}

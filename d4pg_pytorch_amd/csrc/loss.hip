@@ -18,6 +18,7 @@
 //        dL/dlogit_i = q_i (g_i - sum_k g_k q_k),  g_i = (1/N)(-(m_i/q_i)[log q_i>-100] + ((1-m_i)/(1-q_i))[log(1-q_i)>-100])
 //   CE : L = -sum_i m_i log q_i;  dL/dlogit_i = q_i sum(m) - m_i
 #include "common.h"
+#include "loss_dev.h"
 
 constexpr int MAX_ATOM_SLOTS = 4;   // supports up to 256 atoms (4 per lane); kernels are instantiated per slot count
 
@@ -48,112 +49,24 @@ __global__ __launch_bounds__(256) void d4pg_critic_loss_kernel(const D4pgLossArg
     const int b = blockIdx.x * 4 + wave;
     if (b >= a.B) return;   // whole wave exits together (no block-level barrier below)
     const int N = a.N;
-    const float dz = (a.v_max - a.v_min) / (float)(N - 1);
-    const float r = a.reward[b];
-    const float nd = 1.f - a.done[b];
     const float g = a.fixed_gamma >= 0.f ? a.fixed_gamma : a.gamma[b];
     const float w = a.weights ? a.weights[b] : 1.f;
-    float* sp = s_p[wave];
-    float* sb = s_beta[wave];
-
-    // ---- target softmax + beta_j ----
-    float lt[SLOTS], lo[SLOTS];
-    float mx_t = -INFINITY, mx_o = -INFINITY;
+    float lt[SLOTS], lo[SLOTS], m[SLOTS], dl[SLOTS];
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
         const int j = lane + 64 * s;
         lt[s] = j < N ? a.logits_t[(size_t)b * a.ld + j] : -INFINITY;
         lo[s] = j < N ? a.logits[(size_t)b * a.ld + j] : -INFINITY;
-        mx_t = fmaxf(mx_t, lt[s]);
-        mx_o = fmaxf(mx_o, lo[s]);
     }
-    mx_t = wave_max(mx_t);
-    mx_o = wave_max(mx_o);
-    float sum_t = 0.f, sum_o = 0.f;
-#pragma unroll
-    for (int s = 0; s < SLOTS; ++s) {
-        const int j = lane + 64 * s;
-        lt[s] = j < N ? __expf(lt[s] - mx_t) : 0.f;
-        lo[s] = j < N ? __expf(lo[s] - mx_o) : 0.f;
-        sum_t += lt[s];
-        sum_o += lo[s];
-    }
-    sum_t = wave_sum(sum_t);
-    sum_o = wave_sum(sum_o);
-    const float inv_t = 1.f / sum_t, inv_o = 1.f / sum_o;
-#pragma unroll
-    for (int s = 0; s < SLOTS; ++s) {
-        const int j = lane + 64 * s;
-        if (j < N) {
-            const float z = a.v_min + dz * (float)j;
-            float tz = r + nd * g * z;
-            tz = fminf(a.v_max, fmaxf(a.v_min, tz));
-            sp[j] = lt[s] * inv_t;
-            sb[j] = (tz - a.v_min) / dz;
-        }
-    }
-    // LDS rows are private to this wave; wave-level execution order suffices,
-    // the builtin keeps the compiler from reordering the LDS accesses.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-    // ---- dense projection: lane owns destination atoms i = lane + 64 s ----
-    float m[SLOTS];
-#pragma unroll
-    for (int s = 0; s < SLOTS; ++s) m[s] = 0.f;
-#pragma unroll 8
-    for (int j = 0; j < N; ++j) {
-        const float pj = sp[j], bj = sb[j];   // LDS broadcast reads
-#pragma unroll
-        for (int s = 0; s < SLOTS; ++s) {
-            const float i = (float)(lane + 64 * s);
-            m[s] += pj * fmaxf(0.f, 1.f - fabsf(bj - i));
-        }
-    }
-
-    // ---- loss + gradient ----
-    float q[SLOTS], gi[SLOTS];
-    float loss = 0.f, gq = 0.f, msum = 0.f;
-#pragma unroll
-    for (int s = 0; s < SLOTS; ++s) {
-        const int i = lane + 64 * s;
-        q[s] = lo[s] * inv_o;
-        gi[s] = 0.f;
-        if (i < N) {
-            if (a.proj_out) a.proj_out[(size_t)b * a.ld + i] = m[s];
-            if (a.use_ce) {
-                // log q from the log-sum-exp form (finite even when q underflows)
-                const float logq = logf(lo[s] > 0.f ? lo[s] : 1e-45f) - logf(sum_o);
-                loss -= m[s] * logq;
-                msum += m[s];
-            } else {
-                const float lq = logf(q[s]);
-                const float l1 = log1pf(-q[s]);
-                const bool live0 = lq > -100.f, live1 = l1 > -100.f;
-                loss -= m[s] * fmaxf(lq, -100.f) + (1.f - m[s]) * fmaxf(l1, -100.f);
-                float gg = 0.f;
-                if (live0) gg -= m[s] / q[s];
-                if (live1) gg += (1.f - m[s]) / (1.f - q[s]);
-                gi[s] = gg / (float)N;
-                gq += gi[s] * q[s];
-            }
-        }
-    }
-    loss = wave_sum(loss);
-    if (a.use_ce) {
-        msum = wave_sum(msum);
-    } else {
-        loss /= (float)N;
-        gq = wave_sum(gq);
-    }
+    const float loss = d4pg_critic_row<SLOTS>(lt, lo, a.reward[b], 1.f - a.done[b], g, N, a.v_min, a.v_max, a.use_ce,
+                                              s_p[wave], s_beta[wave], lane, m, dl);
     const float scale = w * a.inv_B;
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
         const int i = lane + 64 * s;
         if (i < N) {
-            const float dl = a.use_ce ? (q[s] * msum - m[s]) : q[s] * (gi[s] - gq);
-            a.dlogits[(size_t)b * a.ld + i] = dl * scale;
+            if (a.proj_out) a.proj_out[(size_t)b * a.ld + i] = m[s];
+            a.dlogits[(size_t)b * a.ld + i] = dl[s] * scale;
         }
     }
     if (lane == 0) {
@@ -191,39 +104,19 @@ __global__ __launch_bounds__(256) void d4pg_actor_loss_kernel(const D4pgActorLos
     const int b = blockIdx.x * 4 + wave;
     if (b >= a.B) return;
     const int N = a.N;
-    const float dz = (a.v_max - a.v_min) / (float)(N - 1);
-    float e[SLOTS];
-    float mx = -INFINITY;
+    float e[SLOTS], dl[SLOTS];
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
         const int j = lane + 64 * s;
         e[s] = j < N ? a.logits[(size_t)b * a.ld + j] : -INFINITY;
-        mx = fmaxf(mx, e[s]);
     }
-    mx = wave_max(mx);
-    float sum = 0.f, qz = 0.f;
+    const float qv = d4pg_actor_row<SLOTS>(e, N, a.v_min, a.v_max, lane, dl);
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
         const int j = lane + 64 * s;
-        e[s] = j < N ? __expf(e[s] - mx) : 0.f;
-        sum += e[s];
-        qz += e[s] * (a.v_min + dz * (float)j);
+        if (j < N) a.dlogits[(size_t)b * a.ld + j] = a.inv_B * dl[s];
     }
-    sum = wave_sum(sum);
-    qz = wave_sum(qz);
-    const float inv = 1.f / sum;
-    const float qv = qz * inv;
-#pragma unroll
-    for (int s = 0; s < SLOTS; ++s) {
-        const int j = lane + 64 * s;
-        if (j < N) {
-            const float z = a.v_min + dz * (float)j;
-            a.dlogits[(size_t)b * a.ld + j] = -a.inv_B * (e[s] * inv) * (z - qv);
-        }
-    }
-    if (lane == 0) {
-        a.q_out[b] = qv;
-    }
+    if (lane == 0) a.q_out[b] = qv;
 }
 
 D4PG_API int d4pg_actor_loss(const D4pgActorLossArgs* a, hipStream_t stream) {

@@ -52,3 +52,48 @@ D4PG_API int d4pg_nstep(const NstepArgs* a, hipStream_t stream) {
     hipLaunchKernelGGL(nstep_kernel, dim3(blocks), dim3(256), 0, stream, *a);
     return (int)hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------
+// Ornstein-Uhlenbeck exploration noise for batched GPU rollouts (utils/utils.py:9-34):
+//   x <- x + theta (mu - x) + sigma N(0, 1);  out = clip(action + x, low, high)
+// One thread per (env, action dim); normals from Philox-4x32 (Box-Muller), keyed by
+// (seed, call counter) so replays of a captured graph still advance the stream via the
+// device-resident counter.
+struct OuArgs {
+    float* x;                 // [E*A] noise state, updated in place
+    const float* action;      // [E*A]
+    float* out;               // [E*A]
+    const float* sigma;       // [E] per-env sigma (schedule evaluated by the caller) or null
+    unsigned long long* counter;   // device counter, incremented once per call
+    unsigned long long seed;
+    int n;                    // E*A
+    int A;
+    float theta, mu, sigma_const, low, high;
+};
+
+__global__ __launch_bounds__(256) void ou_noise_kernel(const OuArgs a) {
+    const unsigned long long ctr = *a.counter;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < a.n) {
+        uint32_t r[4];
+        philox4x32((uint32_t)i, (uint32_t)ctr, (uint32_t)(ctr >> 32), 0x0u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), r);
+        const float u1 = fmaxf((float)(r[0] >> 8) * (1.0f / 16777216.0f), 1e-7f);
+        const float u2 = (float)(r[1] >> 8) * (1.0f / 16777216.0f);
+        const float nrm = sqrtf(-2.f * logf(u1)) * cosf(6.2831853f * u2);
+        const float sg = a.sigma != nullptr ? a.sigma[i / a.A] : a.sigma_const;
+        float x = a.x[i];
+        x = x + a.theta * (a.mu - x) + sg * nrm;
+        a.x[i] = x;
+        a.out[i] = fminf(a.high, fmaxf(a.low, a.action[i] + x));
+    }
+}
+__global__ void ou_counter_kernel(unsigned long long* c) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *c += 1;
+}
+
+D4PG_API int d4pg_ou_noise(const OuArgs* a, hipStream_t stream) {
+    if (a->n < 1 || a->A < 1) return -1;
+    hipLaunchKernelGGL(ou_noise_kernel, dim3((a->n + 255) / 256), dim3(256), 0, stream, *a);
+    hipLaunchKernelGGL(ou_counter_kernel, dim3(1), dim3(64), 0, stream, a->counter);
+    return (int)hipGetLastError();
+}

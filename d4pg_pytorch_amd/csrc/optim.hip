@@ -13,6 +13,27 @@
 //                       update is driven without the replay-sampling kernel.
 #include "common.h"
 
+// bf16 "shadow" copies of the weight matrices for the fused bf16 pipeline (csrc/fused.hip).
+// The optimiser kernel refreshes them in the same pass that updates the fp32 masters:
+//   forward shadow   Wf[o][i]            rows padded to 16, leading dim padded to 32 (K-contiguous for y = x W^T)
+//   backward shadow  Wb[i - c0][o]       the transpose of input columns [c0, c1) (K-contiguous for dX = dY W)
+// Pads are zero and never written.
+struct ShadowMat {
+    long long w_off;     // offset (floats) of W inside the range handed to the kernel
+    long long f_off;     // forward shadow offset (bf16 elements), -1: none
+    long long b_off;     // backward (transposed) shadow offset, -1: none
+    int out_dim, in_dim, ld;
+    int f_ld, b_ld, b_c0, b_c1;
+    int pad_;
+};
+struct ShadowArgs {
+    __bf16* p_shadow;    // shadows of the online parameters (forward + backward)
+    __bf16* t_shadow;    // shadows of the target parameters (forward only), may be null
+    ShadowMat m[3];
+    int count;           // 0: no shadows (fp32 pipeline)
+    int pad_;
+};
+
 struct AdamPolyakArgs {
     float* p;          // online parameters   [n]
     const float* g;    // gradients           [n]
@@ -31,7 +52,31 @@ struct AdamPolyakArgs {
     float gscale;      // gradient pre-scale (1/world_size after a sum all-reduce)
     int finish_step;   // 1: this is the last kernel of the update -> publish step_done
     int pad_;
+    ShadowArgs sh;
 };
+
+__device__ __forceinline__ void write_shadows(const ShadowArgs& sh, long long e, const f32x4& p, const f32x4* t) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        if (j >= sh.count) break;
+        const ShadowMat& m = sh.m[j];
+        const long long rel = e - m.w_off;
+        if (rel < 0 || rel >= (long long)m.out_dim * m.ld) continue;
+        const int o = (int)(rel / m.ld), i0 = (int)(rel - (long long)o * m.ld);   // 4 elements share row o
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + k;
+            if (i >= m.in_dim) continue;
+            if (m.f_off >= 0) {
+                sh.p_shadow[m.f_off + (long long)o * m.f_ld + i] = (__bf16)p[k];
+                if (sh.t_shadow != nullptr && t != nullptr) sh.t_shadow[m.f_off + (long long)o * m.f_ld + i] = (__bf16)(*t)[k];
+            }
+            if (m.b_off >= 0 && i >= m.b_c0 && i < m.b_c1)
+                sh.p_shadow[m.b_off + (long long)(i - m.b_c0) * m.b_ld + o] = (__bf16)p[k];
+        }
+        break;
+    }
+}
 
 __global__ __launch_bounds__(256) void adam_polyak_kernel(const AdamPolyakArgs a) {
     const float bc1 = a.st->bc1, bc2 = a.st->bc2;
@@ -55,12 +100,14 @@ __global__ __launch_bounds__(256) void adam_polyak_kernel(const AdamPolyakArgs a
         reinterpret_cast<f32x4*>(a.p)[i] = p;
         reinterpret_cast<f32x4*>(a.m)[i] = m;
         reinterpret_cast<f32x4*>(a.v)[i] = v;
+        f32x4 t;
         if (a.t != nullptr) {
-            f32x4 t = reinterpret_cast<f32x4*>(a.t)[i];
+            t = reinterpret_cast<f32x4*>(a.t)[i];
 #pragma unroll
             for (int k = 0; k < 4; ++k) t[k] = (1.f - a.tau) * t[k] + a.tau * p[k];
             reinterpret_cast<f32x4*>(a.t)[i] = t;
         }
+        if (a.sh.count > 0) write_shadows(a.sh, i * 4, p, a.t != nullptr ? &t : nullptr);
     }
     // step_done is read only by the first kernel of the next update
     if (a.finish_step && blockIdx.x == 0) {

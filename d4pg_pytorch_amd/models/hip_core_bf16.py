@@ -1,0 +1,224 @@
+"""Fused row-local bf16 learner update (``compute_dtype: bf16``).
+
+Seven launches per update instead of 23 (see ``csrc/fused.hip``):
+
+====  ===================================================================
+ 1    replay_sample   (same kernel as the fp32 pipeline)
+ 2    critic_phase    target actor -> target critic -> critic -> loss -> dX, per row tile
+ 3    wgrad           dW/db of the three critic layers in one grouped launch
+ 4    adam_polyak     critic Adam + Polyak + bf16 shadow refresh        [all-reduce before]
+ 5    actor_phase     actor -> critic -> expected Q -> dX critic -> dX actor, per row tile
+ 6    wgrad           dW/db of the three actor layers
+ 7    adam_polyak     actor Adam + Polyak + shadow refresh, publishes the step   [all-reduce before]
+====  ===================================================================
+
+Master weights, Adam state, gradients, logits and losses are fp32; only the MFMA
+operands (weights and activations) are rounded to bf16.  The public API, state
+layout and checkpoints are those of :class:`HipCore`.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional
+
+import torch
+
+from ..ops import hip as H
+from .hip_core import HipCore
+from .nets import LayerSlot, NetLayout, ShadowLayout, ShadowSlot, pad16, pad32, refresh_shadows
+
+LDS_PAD = 8
+LDS_LIMIT = 160 * 1024
+
+
+class HipCoreBf16(HipCore):
+    def __init__(self, cfg: Dict, device="cuda", seed: Optional[int] = None):
+        super().__init__(cfg, device, seed)
+        lay, dev = self.layout, self.device
+        B, S, A, Hd, NO = self.B, self.S, self.A, self.Hd, self.NO
+        if B % 16:
+            raise ValueError("the fused bf16 pipeline needs batch_size to be a multiple of 16")
+        self.sl = ShadowLayout.build(lay)
+        self.shadow_online = torch.zeros(self.sl.numel, dtype=torch.bfloat16, device=dev)
+        self.shadow_target = torch.zeros(self.sl.numel, dtype=torch.bfloat16, device=dev)
+        self.Bp = pad32(B)
+
+        def stash(rows):
+            return torch.zeros(pad16(rows), self.Bp, dtype=torch.bfloat16, device=dev)
+        # critic phase stashes
+        self.saT, self.c_h1T, self.c_h2T = stash(S + A), stash(Hd), stash(Hd)
+        self.c_dlT, self.c_dh2T, self.c_dh1T = stash(NO), stash(Hd), stash(Hd)
+        # actor phase stashes
+        self.sT, self.a_h1T, self.a_h2T = stash(S), stash(Hd), stash(Hd)
+        self.a_daT, self.a_dh2T, self.a_dh1T = stash(A), stash(Hd), stash(Hd)
+        self.dims = self._phase_dims()
+        # rows per workgroup: 32 when it fits LDS and leaves enough workgroups, else 16
+        self.mt = 1
+        if B % 32 == 0 and B // 32 >= 64:
+            need = max(H.lib().d4pg_phase_lds_bytes(self.dims, 2, 0), H.lib().d4pg_phase_lds_bytes(self.dims, 2, 1))
+            if need <= LDS_LIMIT:
+                self.mt = 2
+        need = max(H.lib().d4pg_phase_lds_bytes(self.dims, self.mt, 0),
+                   H.lib().d4pg_phase_lds_bytes(self.dims, self.mt, 1))
+        if need > LDS_LIMIT:
+            raise ValueError(f"dense_size={Hd} needs {need} bytes of LDS per workgroup (> {LDS_LIMIT}); "
+                             f"use compute_dtype: fp32")
+        self.refresh_shadows()
+
+    # ------------------------------------------------------------------ shadows
+    def refresh_shadows(self) -> None:
+        refresh_shadows(self.online.flat.detach(), self.shadow_online, self.layout, self.sl)
+        refresh_shadows(self.target.flat.detach(), self.shadow_target, self.layout, self.sl)
+
+    def _after_load(self) -> None:
+        super()._after_load()
+        self.refresh_shadows()
+
+    def set_world(self, world: int) -> None:
+        super().set_world(world)
+        self.dims = self._phase_dims()
+        self.refresh_shadows()          # parameters were just broadcast
+
+    def _restore(self, snap) -> None:
+        super()._restore(snap)
+        self.refresh_shadows()
+
+    def _phase_dims(self) -> H.PhaseDims:
+        cfg = self.cfg
+        d = H.PhaseDims()
+        d.B, d.Bp, d.S, d.A, d.H, d.NO = self.B, self.Bp, self.S, self.A, self.Hd, self.NO
+        d.ldx_in = self.ldx
+        d.ldx = pad32(self.S + self.A) + LDS_PAD
+        d.ldh = pad32(self.Hd) + LDS_PAD
+        d.ldd = pad32(self.NO) + LDS_PAD
+        d.lda_ = pad32(self.A) + LDS_PAD
+        d.nop = pad16(self.NO)
+        d.distributional = 1 if self.distributional else 0
+        d.use_ce = 1 if cfg["critic_loss"] == "ce" else 0
+        d.v_min, d.v_max = self.v_min, self.v_max
+        d.fixed_gamma = -1.0 if cfg["use_per_sample_gamma"] else self.fixed_gamma
+        d.inv_B = self.inv_global_batch
+        d.min_value = max(float(cfg["min_value"]), -3.0e38)
+        d.max_value = min(float(cfg["max_value"]), 3.0e38)
+        return d
+
+    # ------------------------------------------------------------- descriptors
+    def _lw(self, shadow: torch.Tensor, sh: ShadowSlot, flat: torch.Tensor, slot: LayerSlot, back: bool = False) -> H.LayerW:
+        L = H.LayerW()
+        if not back:
+            L.W = shadow[sh.f_off:].data_ptr()
+            L.bias = flat[slot.b_off:].data_ptr()
+            L.ldw, L.ntiles, L.N = sh.f_ld, sh.f_rows // 16, slot.out_dim
+        else:
+            assert sh.b_off >= 0
+            L.W = shadow[sh.b_off:].data_ptr()
+            L.bias = None
+            L.ldw, L.ntiles, L.N = sh.b_ld, sh.b_rows // 16, sh.b_c1 - sh.b_c0
+        return L
+
+    def _wgrad(self, triples) -> None:
+        g = H.WgradGroup()
+        for i, (dyT, xT, slot) in enumerate(triples):
+            d = g.p[i]
+            d.AT, d.BT = dyT.data_ptr(), xT.data_ptr()
+            d.C = self.grad[slot.w_off:].data_ptr()
+            d.rowsum = self.grad[slot.b_off:].data_ptr()
+            d.M, d.N, d.rowsA, d.rowsB, d.ldc = slot.out_dim, slot.in_dim, dyT.shape[0], xT.shape[0], slot.ld
+        g.count, g.Bp = len(triples), self.Bp
+        H._check(H.lib().d4pg_wgrad(g, H.stream_ptr()), "d4pg_wgrad")
+
+    def _shadow_args(self, net: NetLayout, slots, base: int) -> H.ShadowArgs:
+        sa = H.ShadowArgs()
+        sa.p_shadow, sa.t_shadow = self.shadow_online.data_ptr(), self.shadow_target.data_ptr()
+        for i, (s, sh) in enumerate(zip(net.layers, slots)):
+            m = sa.m[i]
+            m.w_off = s.w_off - base
+            m.f_off, m.b_off = sh.f_off, sh.b_off
+            m.out_dim, m.in_dim, m.ld = s.out_dim, s.in_dim, s.ld
+            m.f_ld, m.b_ld, m.b_c0, m.b_c1 = sh.f_ld, sh.b_ld, sh.b_c0, sh.b_c1
+        sa.count = 3
+        return sa
+
+    # ---------------------------------------------------------------- segments
+    def _build_segments(self, source: str) -> List[Callable[[], None]]:
+        cfg, lay, sl = self.cfg, self.layout, self.sl
+        P, T = self.online.flat, self.target.flat
+        SP, ST = self.shadow_online, self.shadow_target
+        al, cl = lay.actor.layers, lay.critic.layers
+        st = self.dev_state.data_ptr()
+        b1, b2 = self.betas
+        dims = self.dims
+
+        def adam_args(net: NetLayout, slots, lr: float, finish: int) -> H.AdamPolyakArgs:
+            a = H.AdamPolyakArgs()
+            r = slice(net.base, net.base + net.numel)
+            a.p, a.g = P[r].data_ptr(), self.grad[r].data_ptr()
+            a.m, a.v = self.adam_m[r].data_ptr(), self.adam_v[r].data_ptr()
+            a.t, a.st, a.n = T[r].data_ptr(), st, net.numel
+            a.lr, a.beta1, a.beta2, a.eps, a.tau = lr, b1, b2, self.eps, self.tau
+            a.gscale, a.finish_step = 1.0, finish
+            a.metrics = self.metrics.data_ptr() if finish else None
+            a.per_loss, a.weights, a.q_val = self.per_loss.data_ptr(), self.weights.data_ptr(), self.q_val.data_ptr()
+            a.B, a.inv_B = self.B, 1.0 / self.B
+            a.sh = self._shadow_args(net, slots, net.base)
+            return a
+
+        def seg_critic() -> None:
+            if source == "replay":
+                self.replay.enqueue_sample(self, do_tick=True)
+            else:
+                H._check(H.lib().d4pg_tick(st, b1, b2, cfg["priority_beta_start"], cfg["priority_beta_end"],
+                                           int(cfg["num_steps_train"]), H.stream_ptr()), "d4pg_tick")
+            a = H.CriticPhaseArgs()
+            a.d = dims
+            a.sa, a.s2 = self.sa.data_ptr(), self.s2a2.data_ptr()
+            a.reward, a.done, a.gamma = self.reward.data_ptr(), self.done.data_ptr(), self.gamma.data_ptr()
+            a.weights = self.weights.data_ptr()
+            for i in range(3):
+                a.ta[i] = self._lw(ST, sl.actor[i], T, al[i])
+                a.tc[i] = self._lw(ST, sl.critic[i], T, cl[i])
+                a.cf[i] = self._lw(SP, sl.critic[i], P, cl[i])
+            a.cb3 = self._lw(SP, sl.critic[2], P, cl[2], back=True)
+            a.cb2 = self._lw(SP, sl.critic[1], P, cl[1], back=True)
+            a.saT, a.h1T, a.h2T = self.saT.data_ptr(), self.c_h1T.data_ptr(), self.c_h2T.data_ptr()
+            a.dlT, a.dh2T, a.dh1T = self.c_dlT.data_ptr(), self.c_dh2T.data_ptr(), self.c_dh1T.data_ptr()
+            a.per_loss, a.priority = self.per_loss.data_ptr(), self.prio.data_ptr()
+            H._check(H.lib().d4pg_critic_phase(a, self.mt, H.stream_ptr()), "d4pg_critic_phase")
+            forked = None
+            if source == "replay" and self.replay.prioritized:
+                main = torch.cuda.current_stream()
+                ev = torch.cuda.Event()
+                ev.record(main)
+                self._side.wait_event(ev)
+                with torch.cuda.stream(self._side):
+                    self.replay.enqueue_priority_update(self.idx, self.prio, self.B)
+                    forked = torch.cuda.Event()
+                    forked.record(self._side)
+            self._wgrad([(self.c_dlT, self.c_h2T, cl[2]), (self.c_dh2T, self.c_h1T, cl[1]),
+                         (self.c_dh1T, self.saT, cl[0])])
+            if forked is not None:
+                torch.cuda.current_stream().wait_event(forked)
+
+        def seg_actor() -> None:
+            H.launch("d4pg_adam_polyak", adam_args(lay.critic, sl.critic, self.lr_critic, 0))
+            a = H.ActorPhaseArgs()
+            a.d = dims
+            a.s = self.s_pi.data_ptr()
+            for i in range(3):
+                a.af[i] = self._lw(SP, sl.actor[i], P, al[i])
+                a.cf[i] = self._lw(SP, sl.critic[i], P, cl[i])
+            a.cb3 = self._lw(SP, sl.critic[2], P, cl[2], back=True)
+            a.cb2 = self._lw(SP, sl.critic[1], P, cl[1], back=True)
+            a.cb1 = self._lw(SP, sl.critic[0], P, cl[0], back=True)
+            a.ab3 = self._lw(SP, sl.actor[2], P, al[2], back=True)
+            a.ab2 = self._lw(SP, sl.actor[1], P, al[1], back=True)
+            a.sT, a.h1T, a.h2T = self.sT.data_ptr(), self.a_h1T.data_ptr(), self.a_h2T.data_ptr()
+            a.daT, a.dh2T, a.dh1T = self.a_daT.data_ptr(), self.a_dh2T.data_ptr(), self.a_dh1T.data_ptr()
+            a.q_val = self.q_val.data_ptr()
+            H._check(H.lib().d4pg_actor_phase(a, self.mt, H.stream_ptr()), "d4pg_actor_phase")
+            self._wgrad([(self.a_daT, self.a_h2T, al[2]), (self.a_dh2T, self.a_h1T, al[1]),
+                         (self.a_dh1T, self.sT, al[0])])
+
+        def seg_finish() -> None:
+            H.launch("d4pg_adam_polyak", adam_args(lay.actor, sl.actor, self.lr_actor, 1))
+
+        return [seg_critic, seg_actor, seg_finish]

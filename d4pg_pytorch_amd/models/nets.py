@@ -221,3 +221,81 @@ class ActorPolicy:
 
     def load_state_dict(self, sd, strict=True):
         self.view.load_state_dict(sd, strict)
+
+
+# ---------------------------------------------------------------------------
+# bf16 shadow weights for the fused bf16 pipeline (csrc/fused.hip)
+# ---------------------------------------------------------------------------
+
+def pad16(n: int) -> int:
+    return (n + 15) // 16 * 16
+
+
+def pad32(n: int) -> int:
+    return (n + 31) // 32 * 32
+
+
+@dataclass(frozen=True)
+class ShadowSlot:
+    """bf16 copies of one weight matrix ``W[out, in]``.
+
+    forward   ``Wf[pad16(out), pad32(in)]``      — B operand of ``y = x W^T`` (K = in, contiguous)
+    backward  ``Wb[pad16(c1-c0), pad32(out)]``   — B operand of ``dX = dY W`` restricted to input
+                                                   columns ``[c0, c1)`` (K = out, contiguous)
+    Offsets are in bf16 elements, 16-byte aligned; ``b_off = -1`` when no transpose is kept.
+    """
+    f_off: int
+    f_rows: int
+    f_ld: int
+    b_off: int
+    b_rows: int
+    b_ld: int
+    b_c0: int
+    b_c1: int
+
+
+@dataclass(frozen=True)
+class ShadowLayout:
+    actor: Tuple[ShadowSlot, ShadowSlot, ShadowSlot]
+    critic: Tuple[ShadowSlot, ShadowSlot, ShadowSlot]
+    numel: int
+
+    @staticmethod
+    def build(lay: "LearnerLayout") -> "ShadowLayout":
+        off = 0
+
+        def slot(s: LayerSlot, back):
+            nonlocal off
+            f_rows, f_ld = pad16(s.out_dim), pad32(s.in_dim)
+            f_off = off
+            off += f_rows * f_ld
+            if back is None:
+                return ShadowSlot(f_off, f_rows, f_ld, -1, 0, 0, 0, 0)
+            c0, c1 = back
+            b_rows, b_ld = pad16(c1 - c0), pad32(s.out_dim)
+            b_off = off
+            off += b_rows * b_ld
+            return ShadowSlot(f_off, f_rows, f_ld, b_off, b_rows, b_ld, c0, c1)
+
+        a, c = lay.actor.layers, lay.critic.layers
+        S, A, Hd = lay.state_dim, lay.action_dim, lay.hidden
+        actor = (slot(a[0], None), slot(a[1], (0, Hd)), slot(a[2], (0, Hd)))
+        # critic layer 1 only ever back-propagates into the action columns
+        critic = (slot(c[0], (S, S + A)), slot(c[1], (0, Hd)), slot(c[2], (0, Hd)))
+        return ShadowLayout(actor, critic, off)
+
+
+def refresh_shadows(flat: torch.Tensor, shadow: torch.Tensor, lay: "LearnerLayout", sl: ShadowLayout) -> None:
+    """Rebuild every bf16 shadow from the fp32 masters with torch ops (initialisation,
+    checkpoint load, data-parallel broadcast; the steady state is maintained by the
+    optimiser kernel)."""
+    with torch.no_grad():
+        shadow.zero_()
+        for net, slots in ((lay.actor, sl.actor), (lay.critic, sl.critic)):
+            for s, sh in zip(net.layers, slots):
+                W = flat[s.w_off: s.w_off + s.w_numel].view(s.out_dim, s.ld)[:, : s.in_dim]
+                f = shadow[sh.f_off: sh.f_off + sh.f_rows * sh.f_ld].view(sh.f_rows, sh.f_ld)
+                f[: s.out_dim, : s.in_dim] = W.to(torch.bfloat16)
+                if sh.b_off >= 0:
+                    b = shadow[sh.b_off: sh.b_off + sh.b_rows * sh.b_ld].view(sh.b_rows, sh.b_ld)
+                    b[: sh.b_c1 - sh.b_c0, : s.out_dim] = W[:, sh.b_c0: sh.b_c1].t().to(torch.bfloat16)

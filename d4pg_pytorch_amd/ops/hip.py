@@ -74,13 +74,23 @@ class D3pgActorLossArgs(C.Structure):
                 ("inv_B", C.c_float)]
 
 
+class ShadowMat(C.Structure):
+    _fields_ = [("w_off", C.c_longlong), ("f_off", C.c_longlong), ("b_off", C.c_longlong),
+                ("out_dim", C.c_int), ("in_dim", C.c_int), ("ld", C.c_int),
+                ("f_ld", C.c_int), ("b_ld", C.c_int), ("b_c0", C.c_int), ("b_c1", C.c_int), ("pad_", C.c_int)]
+
+
+class ShadowArgs(C.Structure):
+    _fields_ = [("p_shadow", vp), ("t_shadow", vp), ("m", ShadowMat * 3), ("count", C.c_int), ("pad_", C.c_int)]
+
+
 class AdamPolyakArgs(C.Structure):
     _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("t", vp), ("st", vp), ("metrics", vp),
                 ("per_loss", vp), ("weights", vp), ("q_val", vp), ("B", C.c_int), ("inv_B", C.c_float),
                 ("n", C.c_longlong),
                 ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("tau", C.c_float), ("gscale", C.c_float),
-                ("finish_step", C.c_int), ("pad_", C.c_int)]
+                ("finish_step", C.c_int), ("pad_", C.c_int), ("sh", ShadowArgs)]
 
 
 class TreeDesc(C.Structure):
@@ -121,6 +131,49 @@ class ScatterBatchArgs(C.Structure):
 class NstepArgs(C.Structure):
     _fields_ = [("reward", vp), ("done", vp), ("trunc", vp), ("R", vp), ("gk", vp), ("nxt", vp),
                 ("d", vp), ("T", C.c_int), ("E", C.c_int), ("n", C.c_int), ("gamma", C.c_float)]
+
+
+class LayerW(C.Structure):
+    _fields_ = [("W", vp), ("bias", vp), ("ldw", C.c_int), ("ntiles", C.c_int), ("N", C.c_int), ("pad_", C.c_int)]
+
+
+class PhaseDims(C.Structure):
+    _fields_ = [("B", C.c_int), ("Bp", C.c_int), ("S", C.c_int), ("A", C.c_int), ("H", C.c_int), ("NO", C.c_int),
+                ("ldx_in", C.c_int), ("ldx", C.c_int), ("ldh", C.c_int), ("ldd", C.c_int), ("lda_", C.c_int),
+                ("nop", C.c_int), ("distributional", C.c_int), ("use_ce", C.c_int),
+                ("v_min", C.c_float), ("v_max", C.c_float), ("fixed_gamma", C.c_float), ("inv_B", C.c_float),
+                ("min_value", C.c_float), ("max_value", C.c_float)]
+
+
+class CriticPhaseArgs(C.Structure):
+    _fields_ = [("d", PhaseDims), ("sa", vp), ("s2", vp), ("reward", vp), ("done", vp), ("gamma", vp),
+                ("weights", vp), ("ta", LayerW * 3), ("tc", LayerW * 3), ("cf", LayerW * 3),
+                ("cb3", LayerW), ("cb2", LayerW),
+                ("saT", vp), ("h1T", vp), ("h2T", vp), ("dlT", vp), ("dh2T", vp), ("dh1T", vp),
+                ("per_loss", vp), ("priority", vp)]
+
+
+class ActorPhaseArgs(C.Structure):
+    _fields_ = [("d", PhaseDims), ("s", vp), ("af", LayerW * 3), ("cf", LayerW * 3),
+                ("cb3", LayerW), ("cb2", LayerW), ("cb1", LayerW), ("ab3", LayerW), ("ab2", LayerW),
+                ("sT", vp), ("h1T", vp), ("h2T", vp), ("daT", vp), ("dh2T", vp), ("dh1T", vp), ("q_val", vp)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [("AT", vp), ("BT", vp), ("C", vp), ("rowsum", vp), ("M", C.c_int), ("N", C.c_int),
+                ("rowsA", C.c_int), ("rowsB", C.c_int), ("ldc", C.c_int),
+                ("tiles_m", C.c_int), ("tiles_n", C.c_int), ("tile_base", C.c_int)]
+
+
+class WgradGroup(C.Structure):
+    _fields_ = [("p", WgradDesc * 3), ("count", C.c_int), ("total_tiles", C.c_int), ("Bp", C.c_int),
+                ("pad_", C.c_int)]
+
+
+class OuArgs(C.Structure):
+    _fields_ = [("x", vp), ("action", vp), ("out", vp), ("sigma", vp), ("counter", vp), ("seed", C.c_ulonglong),
+                ("n", C.c_int), ("A", C.c_int), ("theta", C.c_float), ("mu", C.c_float), ("sigma_const", C.c_float),
+                ("low", C.c_float), ("high", C.c_float)]
 
 
 class DevStateMirror(C.Structure):
@@ -169,6 +222,11 @@ def lib() -> C.CDLL:
             ("d4pg_replay_sample", [C.POINTER(SampleArgs), vp]),
             ("d4pg_scatter_batch", [C.POINTER(ScatterBatchArgs), vp]),
             ("d4pg_nstep", [C.POINTER(NstepArgs), vp]),
+            ("d4pg_critic_phase", [C.POINTER(CriticPhaseArgs), C.c_int, vp]),
+            ("d4pg_actor_phase", [C.POINTER(ActorPhaseArgs), C.c_int, vp]),
+            ("d4pg_phase_lds_bytes", [C.POINTER(PhaseDims), C.c_int, C.c_int]),
+            ("d4pg_wgrad", [C.POINTER(WgradGroup), vp]),
+            ("d4pg_ou_noise", [C.POINTER(OuArgs), vp]),
         ):
             fn = getattr(_lib, name)
             fn.argtypes = argt
