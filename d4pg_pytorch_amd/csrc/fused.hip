@@ -641,14 +641,57 @@ struct WgradDesc {
     int rowsA, rowsB;   // allocated (padded) rows of the stashes: loads are clamped to them
     int ldc;
     int tiles_m, tiles_n, tile_base;
+    // ---- fused optimiser (single-GPU path): where this matrix lives in the flat buffers ----
+    long long w_off, b_off;        // offsets (floats) of W and bias in the flat parameter buffer
+    long long sf_off, sb_off;      // forward / transposed shadow offsets (bf16 elements), -1: none
+    int sf_ld, sb_ld, sb_c0, sb_c1;
 };
 constexpr int WG_MAX = 3;
+
+// Optimiser state for the fused variant: when `p` is non-null every workgroup applies
+// Adam + Polyak + the bf16 shadow refresh to the 32x32 tile of W it has just reduced
+// (and the tn == 0 workgroups to the bias rows), so no separate optimiser launch is
+// needed.  Only valid without data parallelism (the gradient must not need an all-reduce).
+struct WgradAdam {
+    float* p;            // flat online parameters (whole buffer)
+    float* m;
+    float* v;
+    float* t;            // flat target parameters
+    __bf16* p_shadow;
+    __bf16* t_shadow;
+    DevState* st;
+    float* metrics;              // finishing launch only
+    const float* per_loss;
+    const float* weights;
+    const float* q_val;
+    int B;
+    float inv_B;
+    float lr, beta1, beta2, eps, tau;
+    int finish_step;
+};
+
 struct WgradGroup {
     WgradDesc p[WG_MAX];
     int count, total_tiles;
     int Bp;             // K (multiple of 32)
     int pad_;
+    WgradAdam opt;
 };
+
+__device__ __forceinline__ float adam_elem(const WgradAdam& o, long long idx, float g, float step_size,
+                                           float inv_sqrt_bc2, float& t_out) {
+    float m = o.m[idx], v = o.v[idx], p = o.p[idx];
+    m = o.beta1 * m + (1.f - o.beta1) * g;
+    v = o.beta2 * v + (1.f - o.beta2) * g * g;
+    p = p - step_size * (m / (sqrtf(v) * inv_sqrt_bc2 + o.eps));
+    o.m[idx] = m;
+    o.v[idx] = v;
+    o.p[idx] = p;
+    const float t = (1.f - o.tau) * o.t[idx] + o.tau * p;
+    o.t[idx] = t;
+    t_out = t;
+    return p;
+}
 
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGroup g) {
     __shared__ float red[4 * 16 * 64];
@@ -699,20 +742,85 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGroup g) {
         if (lane < 32) cs[wave * 32 + lane] = asum;
     }
     __syncthreads();
+    const WgradAdam& o = g.opt;
+    const bool fuse = o.p != nullptr;
+    float step_size = 0.f, inv_sqrt_bc2 = 0.f;
+    if (fuse) {
+        step_size = o.lr / o.st->bc1;
+        inv_sqrt_bc2 = 1.f / sqrtf(o.st->bc2);
+    }
     const int wv = threadIdx.x >> 6;
+    const int cn = tn * 32 + r;
+    const int cm0 = tm * 32 + 8 * wv + 4 * h;      // this thread finishes rows cm0 .. cm0+3 of column cn
+    f32x4 pnew = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int reg = 4 * wv + i;
-        const float v = red[(0 * 16 + reg) * 64 + lane] + red[(1 * 16 + reg) * 64 + lane] +
-                        red[(2 * 16 + reg) * 64 + lane] + red[(3 * 16 + reg) * 64 + lane];
-        const int cm = tm * 32 + i + 8 * wv + 4 * h;
-        const int cn = tn * 32 + r;
-        if (cm < d.M && cn < d.N) d.C[(size_t)cm * d.ldc + cn] = v;
+        const float gv = red[(0 * 16 + reg) * 64 + lane] + red[(1 * 16 + reg) * 64 + lane] +
+                         red[(2 * 16 + reg) * 64 + lane] + red[(3 * 16 + reg) * 64 + lane];
+        const int cm = cm0 + i;
+        if (cm < d.M && cn < d.N) {
+            d.C[(size_t)cm * d.ldc + cn] = gv;
+            if (fuse) {
+                float tv;
+                const float pv = adam_elem(o, d.w_off + (long long)cm * d.ldc + cn, gv, step_size, inv_sqrt_bc2, tv);
+                pnew[i] = pv;
+                if (d.sf_off >= 0) {
+                    o.p_shadow[d.sf_off + (long long)cm * d.sf_ld + cn] = (__bf16)pv;
+                    o.t_shadow[d.sf_off + (long long)cm * d.sf_ld + cn] = (__bf16)tv;
+                }
+            }
+        }
+    }
+    if (fuse && d.sb_off >= 0 && cn >= d.sb_c0 && cn < d.sb_c1 && cn < d.N) {
+        // transposed shadow: 4 consecutive output rows of one input column -> one 8-byte store
+        __bf16* dst = o.p_shadow + d.sb_off + (long long)(cn - d.sb_c0) * d.sb_ld + cm0;
+        if (cm0 + 3 < d.M) {
+            bf16x4 pk;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pk[i] = (__bf16)pnew[i];
+            *reinterpret_cast<bf16x4*>(dst) = pk;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (cm0 + i < d.M) dst[i] = (__bf16)pnew[i];
+        }
     }
     if (d.rowsum != nullptr && tn == 0 && threadIdx.x < 32) {
         const int cm = tm * 32 + threadIdx.x;
-        if (cm < d.M)
-            d.rowsum[cm] = cs[threadIdx.x] + cs[32 + threadIdx.x] + cs[64 + threadIdx.x] + cs[96 + threadIdx.x];
+        if (cm < d.M) {
+            const float gb = cs[threadIdx.x] + cs[32 + threadIdx.x] + cs[64 + threadIdx.x] + cs[96 + threadIdx.x];
+            d.rowsum[cm] = gb;
+            if (fuse) {
+                float tv;
+                adam_elem(o, d.b_off + cm, gb, step_size, inv_sqrt_bc2, tv);
+            }
+        }
+    }
+    if (fuse && o.finish_step && blockIdx.x == 0) {
+        // fold this update's losses into the metric sums and publish the step
+        // (step_done is read only by the first kernel of the next update)
+        __syncthreads();
+        float vl = 0.f, pl = 0.f;
+        for (int b = threadIdx.x; b < o.B; b += blockDim.x) {
+            vl += o.per_loss[b] * (o.weights ? o.weights[b] : 1.f);
+            pl -= o.q_val[b];
+        }
+        vl = wave_sum(vl);
+        pl = wave_sum(pl);
+        if (lane == 0) {
+            cs[wv] = vl;
+            cs[4 + wv] = pl;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (o.metrics != nullptr) {
+                o.metrics[MET_VALUE_LOSS] += (cs[0] + cs[1] + cs[2] + cs[3]) * o.inv_B;
+                o.metrics[MET_POLICY_LOSS] += (cs[4] + cs[5] + cs[6] + cs[7]) * o.inv_B;
+                o.metrics[MET_COUNT] += 1.f;
+            }
+            o.st->step_done = o.st->step_cur;
+        }
     }
 }
 

@@ -12,6 +12,9 @@ Seven launches per update instead of 23 (see ``csrc/fused.hip``):
  7    adam_polyak     actor Adam + Polyak + shadow refresh, publishes the step   [all-reduce before]
 ====  ===================================================================
 
+Without data parallelism launches 4 and 7 disappear: each wgrad workgroup applies Adam,
+Polyak and the shadow refresh to the weight tile it has just reduced (5 launches per update).
+
 Master weights, Adam state, gradients, logits and losses are fp32; only the MFMA
 operands (weights and activations) are rounded to bf16.  The public API, state
 layout and checkpoints are those of :class:`HipCore`.
@@ -115,16 +118,40 @@ class HipCoreBf16(HipCore):
             L.ldw, L.ntiles, L.N = sh.b_ld, sh.b_rows // 16, sh.b_c1 - sh.b_c0
         return L
 
-    def _wgrad(self, triples) -> None:
+    def _wgrad(self, triples, opt=None) -> None:
+        """dW/db of up to three layers in one launch.  ``opt=(lr, finish)`` additionally applies
+        Adam + Polyak + the shadow refresh inside the same kernel (no data parallelism only)."""
         g = H.WgradGroup()
-        for i, (dyT, xT, slot) in enumerate(triples):
+        for i, (dyT, xT, slot, sh) in enumerate(triples):
             d = g.p[i]
             d.AT, d.BT = dyT.data_ptr(), xT.data_ptr()
             d.C = self.grad[slot.w_off:].data_ptr()
             d.rowsum = self.grad[slot.b_off:].data_ptr()
             d.M, d.N, d.rowsA, d.rowsB, d.ldc = slot.out_dim, slot.in_dim, dyT.shape[0], xT.shape[0], slot.ld
+            d.w_off, d.b_off = slot.w_off, slot.b_off
+            d.sf_off, d.sb_off = sh.f_off, sh.b_off
+            d.sf_ld, d.sb_ld, d.sb_c0, d.sb_c1 = sh.f_ld, sh.b_ld, sh.b_c0, sh.b_c1
         g.count, g.Bp = len(triples), self.Bp
+        if opt is not None:
+            lr, finish = opt
+            o = g.opt
+            o.p, o.t = self.online.flat.data_ptr(), self.target.flat.data_ptr()
+            o.m, o.v = self.adam_m.data_ptr(), self.adam_v.data_ptr()
+            o.p_shadow, o.t_shadow = self.shadow_online.data_ptr(), self.shadow_target.data_ptr()
+            o.st = self.dev_state.data_ptr()
+            o.metrics = self.metrics.data_ptr() if finish else None
+            o.per_loss, o.weights, o.q_val = self.per_loss.data_ptr(), self.weights.data_ptr(), self.q_val.data_ptr()
+            o.B, o.inv_B = self.B, 1.0 / self.B
+            o.lr, o.beta1, o.beta2, o.eps, o.tau = lr, self.betas[0], self.betas[1], self.eps, self.tau
+            o.finish_step = 1 if finish else 0
         H._check(H.lib().d4pg_wgrad(g, H.stream_ptr()), "d4pg_wgrad")
+
+    def _segments(self, source: str):
+        # without data parallelism the optimiser is fused into the weight-gradient kernel
+        key = f"{source}/{'fusedopt' if self.grad_sync is None else 'dp'}"
+        if key not in self._segments_cache:
+            self._segments_cache[key] = self._build_segments(source)
+        return self._segments_cache[key]
 
     def _shadow_args(self, net: NetLayout, slots, base: int) -> H.ShadowArgs:
         sa = H.ShadowArgs()
@@ -147,6 +174,7 @@ class HipCoreBf16(HipCore):
         st = self.dev_state.data_ptr()
         b1, b2 = self.betas
         dims = self.dims
+        fuse_opt = self.grad_sync is None
 
         def adam_args(net: NetLayout, slots, lr: float, finish: int) -> H.AdamPolyakArgs:
             a = H.AdamPolyakArgs()
@@ -193,13 +221,15 @@ class HipCoreBf16(HipCore):
                     self.replay.enqueue_priority_update(self.idx, self.prio, self.B)
                     forked = torch.cuda.Event()
                     forked.record(self._side)
-            self._wgrad([(self.c_dlT, self.c_h2T, cl[2]), (self.c_dh2T, self.c_h1T, cl[1]),
-                         (self.c_dh1T, self.saT, cl[0])])
+            self._wgrad([(self.c_dlT, self.c_h2T, cl[2], sl.critic[2]), (self.c_dh2T, self.c_h1T, cl[1], sl.critic[1]),
+                         (self.c_dh1T, self.saT, cl[0], sl.critic[0])],
+                        opt=(self.lr_critic, False) if fuse_opt else None)
             if forked is not None:
                 torch.cuda.current_stream().wait_event(forked)
 
         def seg_actor() -> None:
-            H.launch("d4pg_adam_polyak", adam_args(lay.critic, sl.critic, self.lr_critic, 0))
+            if not fuse_opt:
+                H.launch("d4pg_adam_polyak", adam_args(lay.critic, sl.critic, self.lr_critic, 0))
             a = H.ActorPhaseArgs()
             a.d = dims
             a.s = self.s_pi.data_ptr()
@@ -215,10 +245,12 @@ class HipCoreBf16(HipCore):
             a.daT, a.dh2T, a.dh1T = self.a_daT.data_ptr(), self.a_dh2T.data_ptr(), self.a_dh1T.data_ptr()
             a.q_val = self.q_val.data_ptr()
             H._check(H.lib().d4pg_actor_phase(a, self.mt, H.stream_ptr()), "d4pg_actor_phase")
-            self._wgrad([(self.a_daT, self.a_h2T, al[2]), (self.a_dh2T, self.a_h1T, al[1]),
-                         (self.a_dh1T, self.sT, al[0])])
+            self._wgrad([(self.a_daT, self.a_h2T, al[2], sl.actor[2]), (self.a_dh2T, self.a_h1T, al[1], sl.actor[1]),
+                         (self.a_dh1T, self.sT, al[0], sl.actor[0])],
+                        opt=(self.lr_actor, True) if fuse_opt else None)
 
         def seg_finish() -> None:
-            H.launch("d4pg_adam_polyak", adam_args(lay.actor, sl.actor, self.lr_actor, 1))
+            if not fuse_opt:
+                H.launch("d4pg_adam_polyak", adam_args(lay.actor, sl.actor, self.lr_actor, 1))
 
         return [seg_critic, seg_actor, seg_finish]

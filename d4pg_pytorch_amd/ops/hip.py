@@ -162,12 +162,21 @@ class ActorPhaseArgs(C.Structure):
 class WgradDesc(C.Structure):
     _fields_ = [("AT", vp), ("BT", vp), ("C", vp), ("rowsum", vp), ("M", C.c_int), ("N", C.c_int),
                 ("rowsA", C.c_int), ("rowsB", C.c_int), ("ldc", C.c_int),
-                ("tiles_m", C.c_int), ("tiles_n", C.c_int), ("tile_base", C.c_int)]
+                ("tiles_m", C.c_int), ("tiles_n", C.c_int), ("tile_base", C.c_int),
+                ("w_off", C.c_longlong), ("b_off", C.c_longlong), ("sf_off", C.c_longlong), ("sb_off", C.c_longlong),
+                ("sf_ld", C.c_int), ("sb_ld", C.c_int), ("sb_c0", C.c_int), ("sb_c1", C.c_int)]
+
+
+class WgradAdam(C.Structure):
+    _fields_ = [("p", vp), ("m", vp), ("v", vp), ("t", vp), ("p_shadow", vp), ("t_shadow", vp), ("st", vp),
+                ("metrics", vp), ("per_loss", vp), ("weights", vp), ("q_val", vp), ("B", C.c_int),
+                ("inv_B", C.c_float), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
+                ("eps", C.c_float), ("tau", C.c_float), ("finish_step", C.c_int)]
 
 
 class WgradGroup(C.Structure):
     _fields_ = [("p", WgradDesc * 3), ("count", C.c_int), ("total_tiles", C.c_int), ("Bp", C.c_int),
-                ("pad_", C.c_int)]
+                ("pad_", C.c_int), ("opt", WgradAdam)]
 
 
 class OuArgs(C.Structure):
