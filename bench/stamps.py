@@ -1,0 +1,62 @@
+#!/usr/bin/env python
+"""Per-layer timing inside the fused phase kernels (diagnostic build only).
+
+    D4PG_STAMPS=1 python -m d4pg_pytorch_amd.build --force
+    python bench/stamps.py
+
+Workgroup 0 of ``critic_phase_kernel`` / ``actor_phase_kernel`` stamps the 100 MHz wall
+clock at every layer seam; this script runs a few updates and prints the deltas in µs.
+"""
+import ctypes as C
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from bench import synthetic_rows  # noqa: E402
+from d4pg_pytorch_amd.config import default_config  # noqa: E402
+from d4pg_pytorch_amd.models.core import build_core  # noqa: E402
+from d4pg_pytorch_amd.ops import hip as H  # noqa: E402
+from d4pg_pytorch_amd.replay.hbm_replay import HbmReplay  # noqa: E402
+
+CRITIC = ["zero", "load", "ta1", "ta2", "ta3", "tc1", "tc2", "tc3+cf1", "cf2", "cf3", "loss", "cb3", "cb2"]
+ACTOR = ["zero", "load", "af1", "af2", "af3", "cf1", "cf2", "cf3", "loss", "cb3", "cb2", "cb1", "ab3", "ab2"]
+
+
+def main():
+    batch = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    cfg = default_config(env="LunarLanderContinuous-v2", model="d4pg", batch_size=batch, device="cuda",
+                         v_min=-200.0, v_max=200.0, compute_dtype="bf16", replay_mem_size=100_000)
+    core = build_core(cfg, "cuda")
+    rp = HbmReplay(cfg, "cuda", core.dev_state)
+    core.attach_replay(rp)
+    rp.insert(synthetic_rows(50_000, rp.S, rp.A, rp.row_ld, 0.95, "cuda", 1))
+    fn = H.lib().d4pg_read_stamps
+    acc = None
+    n = 0
+    for it in range(60):
+        core.update_from_replay()
+        torch.cuda.synchronize()
+        buf = (C.c_ulonglong * 64)()
+        assert fn(buf) == 0
+        if it < 10:
+            continue
+        v = list(buf)
+        rows = []
+        for k, names in ((0, CRITIC), (1, ACTOR)):
+            t = [v[k * 32 + 31]] + [v[k * 32 + i] for i in range(len(names))]
+            rows.append([(t[i + 1] - t[i]) / 100.0 for i in range(len(names))])
+        acc = rows if acc is None else [[a + b for a, b in zip(ra, rb)] for ra, rb in zip(acc, rows)]
+        n += 1
+    out = {}
+    for names, r, key in ((CRITIC, acc[0], "critic_phase"), (ACTOR, acc[1], "actor_phase")):
+        out[key] = {nm: round(x / n, 2) for nm, x in zip(names, r)}
+        out[key]["total_us"] = round(sum(r) / n, 2)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

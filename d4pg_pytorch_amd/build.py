@@ -65,6 +65,8 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
         o = os.path.join(objdir, os.path.basename(s) + ".o")
         if force or _stale(o, [s] + headers):
             cmd = [hipcc, "-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-c", s, "-o", o]
+            if os.environ.get("D4PG_STAMPS"):      # diagnostic build: per-layer clock stamps (bench/stamps.py)
+                cmd.insert(1, "-DD4PG_STAMPS")
             if verbose:
                 print(" ".join(cmd), flush=True)
             _run(cmd)

@@ -42,10 +42,31 @@ struct DevState {
 // Device metric accumulator layout (floats).
 enum { MET_VALUE_LOSS = 0, MET_POLICY_LOSS = 1, MET_COUNT = 2, MET_Q_MEAN = 3 };
 
+// Offset (bf16 elements) of element (n, k) of a B operand in the packed "fragment order"
+// used by the fused bf16 pipeline: [n / 16][k / 32][(k % 32) / 8][n % 16][k % 8], i.e. the
+// 64 lanes x 8 elements that one wave feeds to v_mfma_f32_16x16x32_bf16 for output tile
+// n / 16 and K-step k / 32 are one contiguous 1 KB block.  ks = K / 32 (K padded to 32).
+__host__ __device__ __forceinline__ long long packed_off(int n, int k, int ks) {
+    return (((((long long)(n >> 4) * ks + (k >> 5)) * 4 + ((k & 31) >> 3)) * 16 + (n & 15)) << 3) + (k & 7);
+}
+
+// Wave-wide reductions on the DPP lane-permute path of the VALU (quad_perm, row_ror):
+// four VALU ops reduce each row of 16 lanes, three more combine the four rows through
+// v_readlane.  (__shfl_xor compiles to ds_bpermute_b32: six dependent LDS-pipe round
+// trips per reduction.)  Every lane returns the same value.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row_lane(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_mov<0xb1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4e>(v);    // quad_perm [2,3,0,1]
+    v += dpp_mov<0x124>(v);   // row_ror 4
+    v += dpp_mov<0x128>(v);   // row_ror 8
+    return (row_lane(v, 0) + row_lane(v, 16)) + (row_lane(v, 32) + row_lane(v, 48));
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
@@ -53,14 +74,18 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_mov<0xb1>(v));
+    v = fmaxf(v, dpp_mov<0x4e>(v));
+    v = fmaxf(v, dpp_mov<0x124>(v));
+    v = fmaxf(v, dpp_mov<0x128>(v));
+    return fmaxf(fmaxf(row_lane(v, 0), row_lane(v, 16)), fmaxf(row_lane(v, 32), row_lane(v, 48)));
 }
 __device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fminf(v, dpp_mov<0xb1>(v));
+    v = fminf(v, dpp_mov<0x4e>(v));
+    v = fminf(v, dpp_mov<0x124>(v));
+    v = fminf(v, dpp_mov<0x128>(v));
+    return fminf(fminf(row_lane(v, 0), row_lane(v, 16)), fminf(row_lane(v, 32), row_lane(v, 48)));
 }
 
 // Philox-4x32-10 counter-based generator (one call = 4 x 32 random bits).

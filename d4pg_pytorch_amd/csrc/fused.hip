@@ -28,13 +28,30 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+// Diagnostic build (-DD4PG_STAMPS): workgroup 0 records the 100 MHz wall clock at every layer
+// seam of the phase kernels; read back with d4pg_read_stamps (bench/stamps.py).
+#ifdef D4PG_STAMPS
+__device__ unsigned long long g_stamps[2][32];
+#define STAMP(k, i)                                                                  \
+    do {                                                                             \
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_stamps[k][i] = wall_clock64();    \
+    } while (0)
+#define STAMP_SYNC() __syncthreads()
+D4PG_API int d4pg_read_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps));
+}
+#else
+#define STAMP(k, i)
+#define STAMP_SYNC()
+#endif
+
 constexpr int NW = 8;          // waves per workgroup (2 per SIMD: twice the weight bytes in flight)
 constexpr int LDS_PAD = 8;     // bf16 elements appended to every LDS row (16 B: breaks the bank stride)
 
 struct LayerW {
-    const __bf16* W;     // shadow [ntiles*16][ldw], K-contiguous, zero padded
-    const float* bias;   // fp32 [N] or null
-    int ldw;             // = K32 of this layer (multiple of 32)
+    const __bf16* W;     // packed shadow (common.h, packed_off): [ntiles][ks][64 lanes][8], zero padded
+    const float* bias;   // fp32 [N]; a zero vector for bias-free (backward) layers, never null
+    int ks;              // K / 32 (K-steps of one MFMA)
     int ntiles;          // output tiles of 16 columns
     int N;               // true number of outputs
     int pad_;
@@ -42,98 +59,123 @@ struct LayerW {
 
 // ---------------------------------------------------------------------------------------
 // One layer on a row tile held in LDS:  epi(row, col, sum_k A[row][k] * W[col][k]).
-// A : LDS bf16 [16*MT][lda] (zero padded to K32).  Wave w owns output tiles w, w+4, ...;
-// the B fragments of a tile (KS loads of 16 B per lane) are all issued before its MFMAs
-// and the next tile's are issued before this tile's MFMAs start (two register sets).
+// A : LDS bf16 [16*MT][lda] (zero padded to K).  Wave w owns output tiles w, w+NW, ...
+// The B fragment of (tile, k-step) is ONE contiguous 1 KB block of the packed shadow, so a
+// wave-wide 16-byte load touches 8 whole cache lines (row-major weights touch 16 half
+// lines per load and stream at half the rate: 5.1 vs 2.45 us per 400x416 layer and CU).
 // C/D map of 16x16x32: col = lane & 15, row = 4 * (lane >> 4) + reg.
+//
+// Latency hiding across the layer chain: the weights of layer i+1 do not depend on the
+// activations of layer i, so every layer function takes a `pre` callable that it invokes
+// as soon as it has issued its own last weight load; `pre` issues the first loads of the
+// NEXT layer (into registers owned by the kernel body), which then land while this
+// layer's last MFMAs, its epilogue and the workgroup barrier run.
 // ---------------------------------------------------------------------------------------
 template <int KS>
-__device__ __forceinline__ void load_b(bf16x8 (&b)[KS], const __bf16* __restrict__ wrow) {
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) b[ks] = *reinterpret_cast<const bf16x8*>(wrow + ks * 32);
+struct TileB {
+    bf16x8 b[KS];
+    float bias;
+};
+
+// The bias of a tile is fetched TOGETHER with (ahead of) that tile's B fragments: vmcnt
+// retires in issue order, so a bias load issued in the epilogue would sit behind the next
+// tile's prefetch and drain it before every epilogue.
+// Returns the RAW load (column clamped into range): any arithmetic on the value here would
+// make the wave wait for the load right after issuing it.  use_bias() masks the padding
+// columns when the epilogue consumes it.
+__device__ __forceinline__ float load_bias(const LayerW& L, int nt, int c) {
+    const int col = nt * 16 + c;
+    const int cc = col < L.N ? col : 0;
+    return L.bias[cc];      // never null: bias-free layers point at a zero vector
+}
+__device__ __forceinline__ float use_bias(const LayerW& L, int nt, int c, float raw) {
+    return (nt * 16 + c) < L.N ? raw : 0.f;
 }
 
-template <int MT, int KS, typename F>
-__device__ __forceinline__ void mma_tile(const bf16x8 (&b)[KS], float bias, const __bf16* A, int lda, int lane, int nt,
-                                         F&& epi) {
-    const int c = lane & 15, kg = lane >> 4;
-    f32x4 acc[MT];
+// Returns a FRESH value: the registers of a tile that does not exist stay undefined (and are
+// never consumed) instead of carrying the previous tile's contents, which would keep a whole
+// register set alive across every conditional prefetch.
+template <int KS>
+__device__ __forceinline__ TileB<KS> fetch_tile(const LayerW& L, int nt, int lane) {
+    TileB<KS> t;
+    if (nt < L.ntiles) {   // wave-uniform
+        t.bias = load_bias(L, nt, lane & 15);
+        const __bf16* p = L.W + ((size_t)nt * KS * 64 + lane) * 8;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(A + (mt * 16 + c) * lda + ks * 32 + 8 * kg);
-            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[ks], acc[mt], 0, 0, 0);
-        }
+        for (int ks = 0; ks < KS; ++ks) t.b[ks] = *reinterpret_cast<const bf16x8*>(p + ks * 512);
     }
-    const int col = nt * 16 + c;
+    return t;
+}
+
+// Hidden-K layer, K-steps known at compile time (L.ks == KS).  `t` already holds the wave's
+// first tile (issued by the previous layer's `pre`) and is refilled in place with the wave's
+// further tiles right after the MFMAs that consumed it, ahead of the epilogue.  The eight
+// waves of the workgroup keep ~100 KB of weight loads in flight between them, which is what
+// one CU needs to stream from L2 at its full rate.
+// `pre` is called at ONE place, before the tile loop: prefetch registers that are defined
+// on several control-flow paths get merged with register copies, and a copy of a register
+// with a load in flight waits for that load.
+template <int MT, int KS, typename F>
+__device__ __forceinline__ void ct_epilogue(const f32x4 (&acc)[MT], float bias, int nt, int lane, F&& epi) {
+    const int col = nt * 16 + (lane & 15);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         f32x4 v = acc[mt];
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += bias;
-        epi(mt * 16 + 4 * kg, col, v);      // 4 consecutive rows of one column
+        epi(mt * 16 + 4 * (lane >> 4), col, v);      // 4 consecutive rows of one column
     }
 }
 
-// The bias of a tile is fetched TOGETHER with (ahead of) that tile's B fragments: vmcnt
-// retires in issue order, so a bias load issued in the epilogue would sit behind the next
-// tile's prefetch and drain it before every epilogue.
-__device__ __forceinline__ float load_bias(const LayerW& L, int nt, int c) {
-    const int col = nt * 16 + c;
-    const int cc = col < L.N ? col : 0;
-    const float v = L.bias != nullptr ? L.bias[cc] : 0.f;
-    return col < L.N ? v : 0.f;
-}
-
-template <int MT, int KS, typename F>
-__device__ __forceinline__ void layer_ct(const __bf16* A, int lda, const LayerW& L, F&& epi) {
+template <int MT, int KS, typename F, typename P>
+__device__ __forceinline__ void layer_ct(TileB<KS>& t, const __bf16* A, int lda, const LayerW& L, F&& epi, P&& pre) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 15, kg = lane >> 4;
-    const __bf16* wbase = L.W + (size_t)c * L.ldw + 8 * kg;
-    const size_t tstride = (size_t)16 * L.ldw;
-    bf16x8 b0[KS], b1[KS];
-    float bias0 = 0.f, bias1 = 0.f;
+    pre();
     int nt = wave;
-    if (nt < L.ntiles) {
-        bias0 = load_bias(L, nt, c);
-        load_b<KS>(b0, wbase + nt * tstride);
-    }
-    for (; nt < L.ntiles; nt += 2 * NW) {
-        const bool has1 = nt + NW < L.ntiles;
-        if (has1) {
-            bias1 = load_bias(L, nt + NW, c);
-            load_b<KS>(b1, wbase + (nt + NW) * tstride);
-        }
-        mma_tile<MT, KS>(b0, bias0, A, lda, lane, nt, epi);
-        if (has1) {
-            if (nt + 2 * NW < L.ntiles) {
-                bias0 = load_bias(L, nt + 2 * NW, c);
-                load_b<KS>(b0, wbase + (nt + 2 * NW) * tstride);
+    if (nt >= L.ntiles) return;
+    for (;;) {
+        f32x4 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(A + (mt * 16 + c) * lda + ks * 32 + 8 * kg);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, t.b[ks], acc[mt], 0, 0, 0);
             }
-            mma_tile<MT, KS>(b1, bias1, A, lda, lane, nt + NW, epi);
+        }
+        const float bias = use_bias(L, nt, c, t.bias);
+        const int nn = nt + NW;
+        if (nn < L.ntiles) {
+            t = fetch_tile<KS>(L, nn, lane);
+            ct_epilogue<MT, KS>(acc, bias, nt, lane, epi);
+            nt = nn;
+        } else {
+            ct_epilogue<MT, KS>(acc, bias, nt, lane, epi);
+            break;
         }
     }
 }
 
-// Runtime-K variant for the narrow layers (inputs, logits, actions): K32 <= 128 typically.
+// Generic layer (any K-steps, any tile count): no register staging beyond one k-step,
+// no prefetch.  Used for hidden sizes without a compile-time variant and for narrow-K
+// layers that exceed the register block of layer_rt.
 template <int MT, typename F>
-__device__ __forceinline__ void layer_rt(const __bf16* A, int lda, const LayerW& L, F&& epi) {
+__device__ __forceinline__ void layer_gen(const __bf16* A, int lda, const LayerW& L, int first_tile, F&& epi) {
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 15, kg = lane >> 4;
-    const int ksteps = L.ldw >> 5;
-    for (int nt = wave; nt < L.ntiles; nt += NW) {
-        const __bf16* wrow = L.W + (size_t)(nt * 16 + c) * L.ldw + 8 * kg;
+    for (int nt = first_tile; nt < L.ntiles; nt += NW) {
+        const __bf16* p = L.W + ((size_t)nt * L.ks * 64 + lane) * 8;
+        const float bias = load_bias(L, nt, c);
         f32x4 acc[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
-        for (int ks = 0; ks < ksteps; ++ks) {
-            const bf16x8 b = *reinterpret_cast<const bf16x8*>(wrow + ks * 32);
+        for (int ks = 0; ks < L.ks; ++ks) {
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(p + ks * 512);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(A + (mt * 16 + c) * lda + ks * 32 + 8 * kg);
@@ -141,25 +183,141 @@ __device__ __forceinline__ void layer_rt(const __bf16* A, int lda, const LayerW&
             }
         }
         const int col = nt * 16 + c;
-        const float bias = (L.bias != nullptr && col < L.N) ? L.bias[col] : 0.f;
+        const float bv = use_bias(L, nt, c, bias);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             f32x4 v = acc[mt];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += bias;
+            for (int r = 0; r < 4; ++r) v[r] += bv;
             epi(mt * 16 + 4 * kg, col, v);
         }
     }
 }
 
-// Hidden-K layers use the compile-time variant when KSH > 0, else the runtime one.
-template <int MT, int KSH, typename F>
-__device__ __forceinline__ void layer_h(const __bf16* A, int lda, const LayerW& L, F&& epi) {
-    if constexpr (KSH > 0)
-        layer_ct<MT, KSH>(A, lda, L, epi);
-    else
-        layer_rt<MT>(A, lda, L, epi);
+// Narrow-K layers (inputs, logits, actions: K <= 128): the wave's whole share of the
+// layer (up to RT_T tiles x RT_K k-steps) is loaded in one burst, normally by the previous
+// layer's `pre`, so the layer itself starts on its MFMAs.
+constexpr int RT_T = 4;
+template <int RT_K>
+struct RtB {
+    bf16x8 b[RT_T][RT_K];
+    float bias[RT_T];
+};
+
+template <int RT_K>
+__device__ __forceinline__ RtB<RT_K> fetch_rt(const LayerW& L, int wave, int lane) {
+    RtB<RT_K> r;                  // fresh value, see fetch_tile
+    if (L.ks > RT_K) return r;    // layer_rt falls back to layer_gen
+#pragma unroll
+    for (int t = 0; t < RT_T; ++t) {
+        const int nt = wave + t * NW;
+        if (nt < L.ntiles) {
+            r.bias[t] = load_bias(L, nt, lane & 15);
+            const __bf16* p = L.W + ((size_t)nt * L.ks * 64 + lane) * 8;
+#pragma unroll
+            for (int ks = 0; ks < RT_K; ++ks)
+                if (ks < L.ks) r.b[t][ks] = *reinterpret_cast<const bf16x8*>(p + ks * 512);
+        }
+    }
+    return r;
 }
+
+template <int MT, int RT_K, typename F, typename P>
+__device__ __forceinline__ void layer_rt(const RtB<RT_K>& r, const __bf16* A, int lda, const LayerW& L, F&& epi, P&& pre) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 15, kg = lane >> 4;
+    if (L.ks > RT_K) {
+        pre();
+        layer_gen<MT>(A, lda, L, wave, epi);
+        return;
+    }
+    // all MFMAs of the wave's register block first: the wait for `r` must come BEFORE the
+    // prefetch is issued (the compiler cannot count loads behind the runtime predicates
+    // and waits for everything in flight)
+    f32x4 acc[RT_T][MT];
+#pragma unroll
+    for (int t = 0; t < RT_T; ++t) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (wave + t * NW < L.ntiles) {
+#pragma unroll
+            for (int ks = 0; ks < RT_K; ++ks) {
+                if (ks < L.ks) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const bf16x8 a = *reinterpret_cast<const bf16x8*>(A + (mt * 16 + c) * lda + ks * 32 + 8 * kg);
+                        acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, r.b[t][ks], acc[t][mt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    float bv[RT_T];
+#pragma unroll
+    for (int t = 0; t < RT_T; ++t) bv[t] = use_bias(L, wave + t * NW, c, r.bias[t]);
+    pre();
+#pragma unroll
+    for (int t = 0; t < RT_T; ++t) {
+        const int nt = wave + t * NW;
+        if (nt < L.ntiles) {
+            const int col = nt * 16 + c;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                f32x4 v = acc[t][mt];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) v[rr] += bv[t];
+                epi(mt * 16 + 4 * kg, col, v);
+            }
+        }
+    }
+    // more than RT_T tiles per wave (hidden sizes above 16 * RT_T * NW): stream the rest
+    layer_gen<MT>(A, lda, L, wave + RT_T * NW, epi);
+}
+
+// Per-kernel prefetch state + dispatch.  Two register sets (slots) alternate along the chain
+// of hidden-K layers: the layer running out of slot X prefetches its successor into slot
+// 1 - X (or into the narrow-K block).  Hidden-K layers run layer_ct when the kernel was
+// instantiated for that K (KSH > 0), else the generic path.
+template <int MT, int KSH, int KSN>
+struct Chain {
+    TileB<(KSH > 0 ? KSH : 1)> t0, t1;   // first tile of the next hidden-K layer (slot 0 / 1)
+    RtB<KSN> nr;                         // the next narrow-K layer (up to KSN K-steps)
+    int wave, lane;
+    __device__ __forceinline__ Chain() {
+        lane = threadIdx.x & 63;
+        wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    }
+    template <int SLOT>
+    __device__ __forceinline__ void prefetch_h(const LayerW& L) {
+        if constexpr (KSH > 0) {
+            if constexpr (SLOT == 0)
+                t0 = fetch_tile<KSH>(L, wave, lane);
+            else
+                t1 = fetch_tile<KSH>(L, wave, lane);
+        }
+    }
+    __device__ __forceinline__ void prefetch_n(const LayerW& L) { nr = fetch_rt<KSN>(L, wave, lane); }
+    template <int SLOT, typename F, typename P>
+    __device__ __forceinline__ void hidden(const __bf16* A, int lda, const LayerW& L, F&& epi, P&& pre) {
+        if constexpr (KSH > 0) {
+            if constexpr (SLOT == 0)
+                layer_ct<MT, KSH>(t0, A, lda, L, epi, pre);
+            else
+                layer_ct<MT, KSH>(t1, A, lda, L, epi, pre);
+        } else {
+            pre();
+            layer_gen<MT>(A, lda, L, wave, epi);
+        }
+    }
+    template <typename F, typename P>
+    __device__ __forceinline__ void narrow(const __bf16* A, int lda, const LayerW& L, F&& epi, P&& pre) {
+        layer_rt<MT, KSN>(nr, A, lda, L, epi, pre);
+    }
+};
+
+// tanh through one v_exp_f32: 1 - 2 / (e^{2x} + 1); exact at +-inf, |error| < 2e-7
+__device__ __forceinline__ float fast_tanh(float x) { return 1.f - 2.f / (__expf(2.f * x) + 1.f); }
 
 // ---- epilogue helpers -------------------------------------------------------------------
 // 4 consecutive rows (row0..row0+3) of one column -> LDS column write
@@ -216,32 +374,46 @@ struct CriticPhaseArgs {
     float* priority;
 };
 
-__device__ __forceinline__ void zero_lds(char* smem, int bytes) {
+// zero `bytes` (multiple of 16) of LDS
+__device__ __forceinline__ void zero_block(void* buf, int bytes) {
     for (int i = threadIdx.x * 16; i < bytes; i += blockDim.x * 16)
-        *reinterpret_cast<f32x4*>(smem + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>((char*)buf + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+// zero the K-padding tail of every row of an M-row bf16 LDS tile: columns [c0 & ~7, ld)
+// (ld is a multiple of 8, so every chunk is an aligned 16-byte store; columns c0 & ~7 .. c0
+// are rewritten by the producing layer's epilogue afterwards)
+__device__ __forceinline__ void zero_tail(__bf16* buf, int ld, int M, int c0) {
+    const int a0 = c0 & ~7, chunks = (ld - a0) >> 3;
+    for (int i = threadIdx.x; i < M * chunks; i += blockDim.x) {
+        const int r = i / chunks, c = i - r * chunks;
+        *reinterpret_cast<f32x4*>(buf + r * ld + a0 + 8 * c) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 }
 
-// load `ncols` fp32 columns of M rows into a bf16 LDS tile (+ optional transposed stash)
+// Load `ncols` fp32 columns of M rows into a bf16 LDS tile whose remaining columns (up to
+// ld_dst) are written as zeros, so the tile needs no separate clearing pass; optionally
+// also into a transposed global stash.
 __device__ __forceinline__ void load_input(const float* __restrict__ src, int ld_src, int row0, int M, int ncols,
                                            __bf16* dst, int ld_dst, __bf16* stashT, int ldt) {
-    for (int i = threadIdx.x; i < M * ncols; i += blockDim.x) {
-        const int r = i / ncols, c = i - r * ncols;
-        const float v = src[(size_t)(row0 + r) * ld_src + c];
+    for (int i = threadIdx.x; i < M * ld_dst; i += blockDim.x) {
+        const int r = i / ld_dst, c = i - r * ld_dst;
+        float v = 0.f;
+        if (c < ncols) {
+            v = src[(size_t)(row0 + r) * ld_src + c];
+            if (stashT != nullptr) stashT[(size_t)c * ldt + row0 + r] = (__bf16)v;
+        }
         dst[r * ld_dst + c] = (__bf16)v;
-        if (stashT != nullptr) stashT[(size_t)c * ldt + row0 + r] = (__bf16)v;
     }
 }
 
 // Loss of the rows of one tile, one wave per row (SL atom slots per lane: 1 for <= 64 atoms).
 template <int SL, int M>
 __device__ __forceinline__ void critic_rows(const CriticPhaseArgs& a, int row0, int lane, int wave, const float* lg_t,
-                                            const float* lg_o, __bf16* dlg, float* sp, float* sb) {
+                                            const float* lg_o, __bf16* dlg, float* sp, float* sb, const float* rs) {
     const PhaseDims& d = a.d;
     for (int r = wave; r < M; r += NW) {
         const int b = row0 + r;
-        const float g = d.fixed_gamma >= 0.f ? d.fixed_gamma : a.gamma[b];
-        const float w = a.weights ? a.weights[b] : 1.f;
-        const float scale = w * d.inv_B;
+        const float rew = rs[r], nd = rs[M + r], g = rs[2 * M + r], scale = rs[3 * M + r];
         if (d.distributional) {
             float lt[SL], lo[SL], m[SL], dl[SL];
 #pragma unroll
@@ -250,7 +422,7 @@ __device__ __forceinline__ void critic_rows(const CriticPhaseArgs& a, int row0, 
                 lt[s] = j < d.NO ? lg_t[r * d.nop + j] : -INFINITY;
                 lo[s] = j < d.NO ? lg_o[r * d.nop + j] : -INFINITY;
             }
-            const float loss = d4pg_critic_row<SL>(lt, lo, a.reward[b], 1.f - a.done[b], g, d.NO, d.v_min, d.v_max,
+            const float loss = d4pg_critic_row<SL, true>(lt, lo, rew, nd, g, d.NO, d.v_min, d.v_max,
                                                    d.use_ce, sp + wave * 256, sb + wave * 256, lane, m, dl);
 #pragma unroll
             for (int s = 0; s < SL; ++s) {
@@ -266,7 +438,7 @@ __device__ __forceinline__ void critic_rows(const CriticPhaseArgs& a, int row0, 
                 a.priority[b] = fabsf(loss) + 1e-4f;
             }
         } else if (lane == 0) {
-            float y = a.reward[b] + (1.f - a.done[b]) * g * lg_t[r * d.nop];
+            float y = rew + nd * g * lg_t[r * d.nop];
             y = fminf(d.max_value, fmaxf(d.min_value, y));
             const float diff = lg_o[r * d.nop] - y;
             const float l = diff * diff;
@@ -279,7 +451,7 @@ __device__ __forceinline__ void critic_rows(const CriticPhaseArgs& a, int row0, 
     }
 }
 
-template <int MT, int KSH>
+template <int MT, int KSH, int KSN>
 __global__ __launch_bounds__(64 * NW) void critic_phase_kernel(const CriticPhaseArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int M = 16 * MT;
@@ -287,6 +459,9 @@ __global__ __launch_bounds__(64 * NW) void critic_phase_kernel(const CriticPhase
     const int row0 = blockIdx.x * M;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    STAMP(0, 31);
+    Chain<MT, KSH, KSN> ch;
+    ch.prefetch_n(a.ta[0]);
     // ---- carve LDS (every offset a multiple of 16 bytes) ----
     int off = 0;
     auto carve = [&](int bytes) { char* p = smem + off; off += (bytes + 15) & ~15; return p; };
@@ -301,11 +476,34 @@ __global__ __launch_bounds__(64 * NW) void critic_phase_kernel(const CriticPhase
     float* lg_o = (float*)carve(M * d.nop * 4);
     float* sp = (float*)carve(NW * 256 * 4);
     float* sb = (float*)carve(NW * 256 * 4);
-    zero_lds(smem, off);
-    __syncthreads();
+    float* rs = (float*)carve(4 * M * 4);           // reward | 1 - done | gamma | weight / B
+    // per-row scalars of the loss: fetched now (registers), parked in LDS behind the inputs
+    float rs_r = 0.f, rs_nd = 0.f, rs_g = 0.f, rs_w = 0.f;
+    if (threadIdx.x < M) {
+        const int b = row0 + threadIdx.x;
+        rs_r = a.reward[b];
+        rs_nd = 1.f - a.done[b];
+        rs_g = d.fixed_gamma >= 0.f ? d.fixed_gamma : a.gamma[b];
+        rs_w = (a.weights ? a.weights[b] : 1.f) * d.inv_B;
+    }
+    // K-padding columns are never written by an epilogue: clear them once (the matching
+    // weight columns are zero, but LDS garbage could be NaN)
+    zero_block(dlg, M * d.ldd * 2);
+    zero_tail(bufA, d.ldh, M, d.H);
+    zero_tail(bufB, d.ldh, M, d.H);
+    zero_tail(bufC, d.ldh, M, d.H);
+    zero_tail(bufD, d.ldh, M, d.H);
+    STAMP(0, 0);
     load_input(a.sa, d.ldx_in, row0, M, d.S + d.A, xin, d.ldx, a.saT, d.Bp);
     load_input(a.s2, d.ldx_in, row0, M, d.S, xin2, d.ldx, nullptr, 0);
+    if (threadIdx.x < M) {
+        rs[threadIdx.x] = rs_r;
+        rs[M + threadIdx.x] = rs_nd;
+        rs[2 * M + threadIdx.x] = rs_g;
+        rs[3 * M + threadIdx.x] = rs_w;
+    }
     __syncthreads();
+    STAMP(0, 1);
 
     auto relu_to = [&](__bf16* buf) {
         return [=](int r0, int col, f32x4 v) {
@@ -315,70 +513,82 @@ __global__ __launch_bounds__(64 * NW) void critic_phase_kernel(const CriticPhase
         };
     };
     // ---- target actor: s' -> a' (written into the action columns of xin2) ----
-    layer_rt<MT>(xin2, d.ldx, a.ta[0], relu_to(bufA));
+    ch.narrow(xin2, d.ldx, a.ta[0], relu_to(bufA), [&] { ch.template prefetch_h<0>(a.ta[1]); });
     __syncthreads();
-    layer_h<MT, KSH>(bufA, d.ldh, a.ta[1], relu_to(bufB));
+    STAMP(0, 2);
+    ch.template hidden<0>(bufA, d.ldh, a.ta[1], relu_to(bufB), [&] { ch.template prefetch_h<1>(a.ta[2]); });
     __syncthreads();
-    layer_h<MT, KSH>(bufB, d.ldh, a.ta[2], [=](int r0, int col, f32x4 v) {
+    STAMP(0, 3);
+    ch.template hidden<1>(bufB, d.ldh, a.ta[2], [=](int r0, int col, f32x4 v) {
         if (col < d.A) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+            for (int r = 0; r < 4; ++r) v[r] = fast_tanh(v[r]);
             put_lds4(xin2, d.ldx, r0, d.S + col, v);
         }
-    });
+    }, [&] { ch.prefetch_n(a.tc[0]); });
     __syncthreads();
+    STAMP(0, 4);
     // ---- target critic: (s', a') -> logits_t ----
-    layer_rt<MT>(xin2, d.ldx, a.tc[0], relu_to(bufA));
+    ch.narrow(xin2, d.ldx, a.tc[0], relu_to(bufA), [&] { ch.template prefetch_h<0>(a.tc[1]); });
     __syncthreads();
-    layer_h<MT, KSH>(bufA, d.ldh, a.tc[1], relu_to(bufB));
+    STAMP(0, 5);
+    ch.template hidden<0>(bufA, d.ldh, a.tc[1], relu_to(bufB), [&] { ch.template prefetch_h<1>(a.tc[2]); });
     __syncthreads();
-    layer_h<MT, KSH>(bufB, d.ldh, a.tc[2], [=](int r0, int col, f32x4 v) {
+    STAMP(0, 6);
+    ch.template hidden<1>(bufB, d.ldh, a.tc[2], [=](int r0, int col, f32x4 v) {
         if (col < d.nop) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) lg_t[(r0 + r) * d.nop + col] = v[r];
         }
-    });
+    }, [&] { ch.prefetch_n(a.cf[0]); });
     // ---- online critic: (s, a) -> logits, activations stashed (transposed) for wgrad ----
-    layer_rt<MT>(xin, d.ldx, a.cf[0], [=](int r0, int col, f32x4 v) {
+    ch.narrow(xin, d.ldx, a.cf[0], [=](int r0, int col, f32x4 v) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
         put_lds4(bufC, d.ldh, r0, col, v);
         put_stash4(a.h1T, d.Bp, col, row0 + r0, v);
-    });
+    }, [&] { ch.template prefetch_h<0>(a.cf[1]); });
     __syncthreads();
-    layer_h<MT, KSH>(bufC, d.ldh, a.cf[1], [=](int r0, int col, f32x4 v) {
+    STAMP(0, 7);
+    ch.template hidden<0>(bufC, d.ldh, a.cf[1], [=](int r0, int col, f32x4 v) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
         put_lds4(bufD, d.ldh, r0, col, v);
         put_stash4(a.h2T, d.Bp, col, row0 + r0, v);
-    });
+    }, [&] { ch.template prefetch_h<1>(a.cf[2]); });
     __syncthreads();
-    layer_h<MT, KSH>(bufD, d.ldh, a.cf[2], [=](int r0, int col, f32x4 v) {
+    STAMP(0, 8);
+    ch.template hidden<1>(bufD, d.ldh, a.cf[2], [=](int r0, int col, f32x4 v) {
         if (col < d.nop) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) lg_o[(r0 + r) * d.nop + col] = v[r];
         }
-    });
+    }, [&] { ch.prefetch_n(a.cb3); });
     __syncthreads();
+    STAMP(0, 9);
     // ---- loss: one wave per row ----
     if (d.distributional && d.NO <= 64)
-        critic_rows<1, M>(a, row0, lane, wave, lg_t, lg_o, dlg, sp, sb);
+        critic_rows<1, M>(a, row0, lane, wave, lg_t, lg_o, dlg, sp, sb, rs);
     else
-        critic_rows<4, M>(a, row0, lane, wave, lg_t, lg_o, dlg, sp, sb);
+        critic_rows<4, M>(a, row0, lane, wave, lg_t, lg_o, dlg, sp, sb, rs);
     __syncthreads();
+    STAMP(0, 10);
     // ---- backward through critic layers 3 and 2 (activation gradients only) ----
-    layer_rt<MT>(dlg, d.ldd, a.cb3, [=](int r0, int col, f32x4 v) {
+    ch.narrow(dlg, d.ldd, a.cb3, [=](int r0, int col, f32x4 v) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = (float)bufD[(r0 + r) * d.ldh + col] > 0.f ? v[r] : 0.f;
         put_lds4(bufD, d.ldh, r0, col, v);       // in place: each element is read and written by one lane
         put_stash4(a.dh2T, d.Bp, col, row0 + r0, v);
-    });
+    }, [&] { ch.template prefetch_h<0>(a.cb2); });
     __syncthreads();
-    layer_h<MT, KSH>(bufD, d.ldh, a.cb2, [=](int r0, int col, f32x4 v) {
+    STAMP(0, 11);
+    ch.template hidden<0>(bufD, d.ldh, a.cb2, [=](int r0, int col, f32x4 v) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = (float)bufC[(r0 + r) * d.ldh + col] > 0.f ? v[r] : 0.f;
         put_stash4(a.dh1T, d.Bp, col, row0 + r0, v);
-    });
+    }, [] {});
+    STAMP_SYNC();
+    STAMP(0, 12);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -411,7 +621,7 @@ __device__ __forceinline__ void actor_rows(const ActorPhaseArgs& a, int row0, in
                 const int j = lane + 64 * s;
                 e[s] = j < d.NO ? lg_o[r * d.nop + j] : -INFINITY;
             }
-            const float qv = d4pg_actor_row<SL>(e, d.NO, d.v_min, d.v_max, lane, dl);
+            const float qv = d4pg_actor_row<SL, true>(e, d.NO, d.v_min, d.v_max, lane, dl);
 #pragma unroll
             for (int s = 0; s < SL; ++s) {
                 const int j = lane + 64 * s;
@@ -425,7 +635,7 @@ __device__ __forceinline__ void actor_rows(const ActorPhaseArgs& a, int row0, in
     }
 }
 
-template <int MT, int KSH>
+template <int MT, int KSH, int KSN>
 __global__ __launch_bounds__(64 * NW) void actor_phase_kernel(const ActorPhaseArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int M = 16 * MT;
@@ -433,6 +643,9 @@ __global__ __launch_bounds__(64 * NW) void actor_phase_kernel(const ActorPhaseAr
     const int row0 = blockIdx.x * M;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    STAMP(1, 31);
+    Chain<MT, KSH, KSN> ch;
+    ch.prefetch_n(a.af[0]);
     int off = 0;
     auto carve = [&](int bytes) { char* p = smem + off; off += (bytes + 15) & ~15; return p; };
     __bf16* xin = (__bf16*)carve(M * d.ldx * 2);    // [s | pi(s)]
@@ -445,36 +658,44 @@ __global__ __launch_bounds__(64 * NW) void actor_phase_kernel(const ActorPhaseAr
     float* lg_o = (float*)carve(M * d.nop * 4);
     float* pi = (float*)carve(M * 16 * ((d.A + 15) / 16) * 4);
     const int ldpi = 16 * ((d.A + 15) / 16);
-    zero_lds(smem, off);
-    __syncthreads();
+    zero_block(dlg, M * (d.ldd + d.lda_) * 2);      // dlg and dab are adjacent
+    zero_tail(bufA, d.ldh, M, d.H);
+    zero_tail(bufB, d.ldh, M, d.H);
+    zero_tail(bufC, d.ldh, M, d.H);
+    zero_tail(bufD, d.ldh, M, d.H);
+    STAMP(1, 0);
     load_input(a.s, d.ldx_in, row0, M, d.S, xin, d.ldx, a.sT, d.Bp);
     __syncthreads();
+    STAMP(1, 1);
     // ---- actor forward ----
-    layer_rt<MT>(xin, d.ldx, a.af[0], [=](int r0, int col, f32x4 v) {
+    ch.narrow(xin, d.ldx, a.af[0], [=](int r0, int col, f32x4 v) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
         put_lds4(bufA, d.ldh, r0, col, v);
         put_stash4(a.h1T, d.Bp, col, row0 + r0, v);
-    });
+    }, [&] { ch.template prefetch_h<0>(a.af[1]); });
     __syncthreads();
-    layer_h<MT, KSH>(bufA, d.ldh, a.af[1], [=](int r0, int col, f32x4 v) {
+    STAMP(1, 2);
+    ch.template hidden<0>(bufA, d.ldh, a.af[1], [=](int r0, int col, f32x4 v) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
         put_lds4(bufB, d.ldh, r0, col, v);
         put_stash4(a.h2T, d.Bp, col, row0 + r0, v);
-    });
+    }, [&] { ch.template prefetch_h<1>(a.af[2]); });
     __syncthreads();
-    layer_h<MT, KSH>(bufB, d.ldh, a.af[2], [=](int r0, int col, f32x4 v) {
+    STAMP(1, 3);
+    ch.template hidden<1>(bufB, d.ldh, a.af[2], [=](int r0, int col, f32x4 v) {
         if (col < d.A) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                v[r] = tanhf(v[r]);
+                v[r] = fast_tanh(v[r]);
                 pi[(r0 + r) * ldpi + col] = v[r];
             }
             put_lds4(xin, d.ldx, r0, d.S + col, v);
         }
-    });
+    }, [&] { ch.prefetch_n(a.cf[0]); });
     __syncthreads();
+    STAMP(1, 4);
     // ---- critic forward at (s, pi(s)) ----
     auto relu_to = [&](__bf16* buf) {
         return [=](int r0, int col, f32x4 v) {
@@ -483,37 +704,43 @@ __global__ __launch_bounds__(64 * NW) void actor_phase_kernel(const ActorPhaseAr
             put_lds4(buf, d.ldh, r0, col, v);
         };
     };
-    layer_rt<MT>(xin, d.ldx, a.cf[0], relu_to(bufC));
+    ch.narrow(xin, d.ldx, a.cf[0], relu_to(bufC), [&] { ch.template prefetch_h<0>(a.cf[1]); });
     __syncthreads();
-    layer_h<MT, KSH>(bufC, d.ldh, a.cf[1], relu_to(bufD));
+    STAMP(1, 5);
+    ch.template hidden<0>(bufC, d.ldh, a.cf[1], relu_to(bufD), [&] { ch.template prefetch_h<1>(a.cf[2]); });
     __syncthreads();
-    layer_h<MT, KSH>(bufD, d.ldh, a.cf[2], [=](int r0, int col, f32x4 v) {
+    STAMP(1, 6);
+    ch.template hidden<1>(bufD, d.ldh, a.cf[2], [=](int r0, int col, f32x4 v) {
         if (col < d.nop) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) lg_o[(r0 + r) * d.nop + col] = v[r];
         }
-    });
+    }, [&] { ch.prefetch_n(a.cb3); });
     __syncthreads();
+    STAMP(1, 7);
     // ---- actor loss: -mean Q ----
     if (d.distributional && d.NO <= 64)
         actor_rows<1, M>(a, row0, lane, wave, lg_o, dlg);
     else
         actor_rows<4, M>(a, row0, lane, wave, lg_o, dlg);
     __syncthreads();
+    STAMP(1, 8);
     // ---- critic backward (dX only) down to the action ----
-    layer_rt<MT>(dlg, d.ldd, a.cb3, [=](int r0, int col, f32x4 v) {
+    ch.narrow(dlg, d.ldd, a.cb3, [=](int r0, int col, f32x4 v) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = (float)bufD[(r0 + r) * d.ldh + col] > 0.f ? v[r] : 0.f;
         put_lds4(bufD, d.ldh, r0, col, v);
-    });
+    }, [&] { ch.template prefetch_h<0>(a.cb2); });
     __syncthreads();
-    layer_h<MT, KSH>(bufD, d.ldh, a.cb2, [=](int r0, int col, f32x4 v) {
+    STAMP(1, 9);
+    ch.template hidden<0>(bufD, d.ldh, a.cb2, [=](int r0, int col, f32x4 v) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = (float)bufC[(r0 + r) * d.ldh + col] > 0.f ? v[r] : 0.f;
         put_lds4(bufC, d.ldh, r0, col, v);
-    });
+    }, [&] { ch.template prefetch_h<1>(a.cb1); });
     __syncthreads();
-    layer_h<MT, KSH>(bufC, d.ldh, a.cb1, [=](int r0, int col, f32x4 v) {
+    STAMP(1, 10);
+    ch.template hidden<1>(bufC, d.ldh, a.cb1, [=](int r0, int col, f32x4 v) {
         if (col < d.A) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -523,21 +750,25 @@ __global__ __launch_bounds__(64 * NW) void actor_phase_kernel(const ActorPhaseAr
             put_lds4(dab, d.lda_, r0, col, v);
             put_stash4(a.daT, d.Bp, col, row0 + r0, v);
         }
-    });
+    }, [&] { ch.prefetch_n(a.ab3); });
     __syncthreads();
+    STAMP(1, 11);
     // ---- actor backward ----
-    layer_rt<MT>(dab, d.lda_, a.ab3, [=](int r0, int col, f32x4 v) {
+    ch.narrow(dab, d.lda_, a.ab3, [=](int r0, int col, f32x4 v) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = (float)bufB[(r0 + r) * d.ldh + col] > 0.f ? v[r] : 0.f;
         put_lds4(bufB, d.ldh, r0, col, v);
         put_stash4(a.dh2T, d.Bp, col, row0 + r0, v);
-    });
+    }, [&] { ch.template prefetch_h<0>(a.ab2); });
     __syncthreads();
-    layer_h<MT, KSH>(bufB, d.ldh, a.ab2, [=](int r0, int col, f32x4 v) {
+    STAMP(1, 12);
+    ch.template hidden<0>(bufB, d.ldh, a.ab2, [=](int r0, int col, f32x4 v) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = (float)bufA[(r0 + r) * d.ldh + col] > 0.f ? v[r] : 0.f;
         put_stash4(a.dh1T, d.Bp, col, row0 + r0, v);
-    });
+    }, [] {});
+    STAMP_SYNC();
+    STAMP(1, 13);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -545,7 +776,7 @@ __global__ __launch_bounds__(64 * NW) void actor_phase_kernel(const ActorPhaseAr
 static int phase_lds_bytes_critic(const PhaseDims& d, int M) {
     auto al = [](int b) { return (b + 15) & ~15; };
     return 2 * al(M * d.ldx * 2) + 4 * al(M * d.ldh * 2) + al(M * d.ldd * 2) + 2 * al(M * d.nop * 4) +
-           2 * al(NW * 256 * 4);
+           2 * al(NW * 256 * 4) + al(4 * M * 4);
 }
 static int phase_lds_bytes_actor(const PhaseDims& d, int M) {
     auto al = [](int b) { return (b + 15) & ~15; };
@@ -569,10 +800,13 @@ static int max_k32(const PhaseDims& d) {
     return k - LDS_PAD;
 }
 static int check_layer(const LayerW& L, int k32_max) {
-    if (L.W == nullptr || L.ntiles < 1 || (L.ldw & 31) || L.ldw < 32 || L.ldw > k32_max) return -6;
+    if (L.W == nullptr || L.bias == nullptr || L.ntiles < 1 || L.ks < 1 || L.ks * 32 > k32_max) return -6;
     if (((uintptr_t)L.W) & 15) return -7;
     return 0;
 }
+static int max3i(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
+// hidden-K layers run the compile-time path: their K-steps must be the kernel's
+static int check_hidden(const LayerW& L, int ksh) { return L.ks == ksh ? 0 : -10; }
 
 template <typename K, typename Args>
 static int launch_phase(K kernel, const Args& a, int grid, int lds, hipStream_t stream) {
@@ -585,6 +819,15 @@ static int launch_phase(K kernel, const Args& a, int grid, int lds, hipStream_t 
     return (int)hipGetLastError();
 }
 
+// KSN: register block of the narrow-K layers (2 covers inputs / logits up to 64 wide)
+#define DISPATCH_KSH(KERNEL, MTV, KSNV)                                                        \
+    do {                                                                                       \
+        if (ksh == 13) return launch_phase(KERNEL<MTV, 13, KSNV>, *a, grid, lds, stream);      \
+        if (ksh == 4) return launch_phase(KERNEL<MTV, 4, KSNV>, *a, grid, lds, stream);        \
+        if (ksh == 8) return launch_phase(KERNEL<MTV, 8, KSNV>, *a, grid, lds, stream);        \
+        return launch_phase(KERNEL<MTV, 0, KSNV>, *a, grid, lds, stream);                      \
+    } while (0)
+
 #define DISPATCH_PHASE(KERNEL, LDSFN)                                                       \
     const PhaseDims& d = a->d;                                                              \
     const int M = 16 * mt;                                                                  \
@@ -595,31 +838,37 @@ static int launch_phase(K kernel, const Args& a, int grid, int lds, hipStream_t 
     const int grid = d.B / M;                                                               \
     const int ksh = (d.ldh - LDS_PAD) / 32;                                                 \
     if (mt == 1) {                                                                          \
-        if (ksh == 13) return launch_phase(KERNEL<1, 13>, *a, grid, lds, stream);          \
-        if (ksh == 4) return launch_phase(KERNEL<1, 4>, *a, grid, lds, stream);            \
-        if (ksh == 8) return launch_phase(KERNEL<1, 8>, *a, grid, lds, stream);            \
-        return launch_phase(KERNEL<1, 0>, *a, grid, lds, stream);                          \
+        if (ksn <= 2) DISPATCH_KSH(KERNEL, 1, 2);                                           \
+        DISPATCH_KSH(KERNEL, 1, 4);                                                         \
     }                                                                                       \
-    if (ksh == 13) return launch_phase(KERNEL<2, 13>, *a, grid, lds, stream);              \
-    if (ksh == 4) return launch_phase(KERNEL<2, 4>, *a, grid, lds, stream);                \
-    if (ksh == 8) return launch_phase(KERNEL<2, 8>, *a, grid, lds, stream);                \
-    return launch_phase(KERNEL<2, 0>, *a, grid, lds, stream);
+    if (ksn <= 2) DISPATCH_KSH(KERNEL, 2, 2);                                               \
+    DISPATCH_KSH(KERNEL, 2, 4);
 
 D4PG_API int d4pg_critic_phase(const CriticPhaseArgs* a, int mt, hipStream_t stream) {
     const int kmax = max_k32(a->d);
+    const int ksh_ = (a->d.ldh - LDS_PAD) / 32;
     for (int i = 0; i < 3; ++i)
         if (check_layer(a->ta[i], kmax) || check_layer(a->tc[i], kmax) || check_layer(a->cf[i], kmax)) return -6;
     if (check_layer(a->cb3, kmax) || check_layer(a->cb2, kmax)) return -6;
+    for (int i = 1; i < 3; ++i)
+        if (check_hidden(a->ta[i], ksh_) || check_hidden(a->tc[i], ksh_) || check_hidden(a->cf[i], ksh_)) return -10;
+    if (check_hidden(a->cb2, ksh_)) return -10;
+    const int ksn = max3i(a->cb3.ks, a->ta[0].ks, max3i(a->tc[0].ks, a->cf[0].ks, 0));
     DISPATCH_PHASE(critic_phase_kernel, phase_lds_bytes_critic)
 }
 
 D4PG_API int d4pg_actor_phase(const ActorPhaseArgs* a, int mt, hipStream_t stream) {
     const int kmax = max_k32(a->d);
+    const int ksh_ = (a->d.ldh - LDS_PAD) / 32;
     for (int i = 0; i < 3; ++i)
         if (check_layer(a->af[i], kmax) || check_layer(a->cf[i], kmax)) return -6;
     if (check_layer(a->cb3, kmax) || check_layer(a->cb2, kmax) || check_layer(a->cb1, kmax) ||
         check_layer(a->ab3, kmax) || check_layer(a->ab2, kmax))
         return -6;
+    for (int i = 1; i < 3; ++i)
+        if (check_hidden(a->af[i], ksh_) || check_hidden(a->cf[i], ksh_)) return -10;
+    if (check_hidden(a->cb2, ksh_) || check_hidden(a->cb1, ksh_) || check_hidden(a->ab2, ksh_)) return -10;
+    const int ksn = max3i(a->af[0].ks, a->cf[0].ks, max3i(a->cb3.ks, a->ab3.ks, 0));
     DISPATCH_PHASE(actor_phase_kernel, phase_lds_bytes_actor)
 }
 
@@ -766,15 +1015,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGroup g) {
                 const float pv = adam_elem(o, d.w_off + (long long)cm * d.ldc + cn, gv, step_size, inv_sqrt_bc2, tv);
                 pnew[i] = pv;
                 if (d.sf_off >= 0) {
-                    o.p_shadow[d.sf_off + (long long)cm * d.sf_ld + cn] = (__bf16)pv;
-                    o.t_shadow[d.sf_off + (long long)cm * d.sf_ld + cn] = (__bf16)tv;
+                    const long long so = d.sf_off + packed_off(cm, cn, d.sf_ld >> 5);
+                    o.p_shadow[so] = (__bf16)pv;
+                    o.t_shadow[so] = (__bf16)tv;
                 }
             }
         }
     }
     if (fuse && d.sb_off >= 0 && cn >= d.sb_c0 && cn < d.sb_c1 && cn < d.N) {
-        // transposed shadow: 4 consecutive output rows of one input column -> one 8-byte store
-        __bf16* dst = o.p_shadow + d.sb_off + (long long)(cn - d.sb_c0) * d.sb_ld + cm0;
+        // transposed shadow: 4 consecutive output rows (cm0 % 4 == 0) of one input column are 4
+        // consecutive k of one packed row -> one 8-byte store
+        __bf16* dst = o.p_shadow + d.sb_off + packed_off(cn - d.sb_c0, cm0, d.sb_ld >> 5);
         if (cm0 + 3 < d.M) {
             bf16x4 pk;
 #pragma unroll

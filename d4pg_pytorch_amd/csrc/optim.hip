@@ -15,9 +15,9 @@
 
 // bf16 "shadow" copies of the weight matrices for the fused bf16 pipeline (csrc/fused.hip).
 // The optimiser kernel refreshes them in the same pass that updates the fp32 masters:
-//   forward shadow   Wf[o][i]            rows padded to 16, leading dim padded to 32 (K-contiguous for y = x W^T)
-//   backward shadow  Wb[i - c0][o]       the transpose of input columns [c0, c1) (K-contiguous for dX = dY W)
-// Pads are zero and never written.
+//   forward shadow   Wf(n = o, k = i)        rows padded to 16, K padded to 32 (B operand of y = x W^T)
+//   backward shadow  Wb(n = i - c0, k = o)   the transpose of input columns [c0, c1) (B operand of dX = dY W)
+// both stored in the packed fragment order of common.h (packed_off).  Pads are zero and never written.
 struct ShadowMat {
     long long w_off;     // offset (floats) of W inside the range handed to the kernel
     long long f_off;     // forward shadow offset (bf16 elements), -1: none
@@ -68,11 +68,12 @@ __device__ __forceinline__ void write_shadows(const ShadowArgs& sh, long long e,
             const int i = i0 + k;
             if (i >= m.in_dim) continue;
             if (m.f_off >= 0) {
-                sh.p_shadow[m.f_off + (long long)o * m.f_ld + i] = (__bf16)p[k];
-                if (sh.t_shadow != nullptr && t != nullptr) sh.t_shadow[m.f_off + (long long)o * m.f_ld + i] = (__bf16)(*t)[k];
+                const long long so = m.f_off + packed_off(o, i, m.f_ld >> 5);
+                sh.p_shadow[so] = (__bf16)p[k];
+                if (sh.t_shadow != nullptr && t != nullptr) sh.t_shadow[so] = (__bf16)(*t)[k];
             }
             if (m.b_off >= 0 && i >= m.b_c0 && i < m.b_c1)
-                sh.p_shadow[m.b_off + (long long)(i - m.b_c0) * m.b_ld + o] = (__bf16)p[k];
+                sh.p_shadow[m.b_off + packed_off(i - m.b_c0, o, m.b_ld >> 5)] = (__bf16)p[k];
         }
         break;
     }

@@ -44,6 +44,7 @@ class HipCoreBf16(HipCore):
         self.shadow_online = torch.zeros(self.sl.numel, dtype=torch.bfloat16, device=dev)
         self.shadow_target = torch.zeros(self.sl.numel, dtype=torch.bfloat16, device=dev)
         self.Bp = pad32(B)
+        self.zero_bias = torch.zeros(pad16(max(Hd, S + A, NO)), dtype=torch.float32, device=dev)   # bias of the dX layers
 
         def stash(rows):
             return torch.zeros(pad16(rows), self.Bp, dtype=torch.bfloat16, device=dev)
@@ -110,12 +111,12 @@ class HipCoreBf16(HipCore):
         if not back:
             L.W = shadow[sh.f_off:].data_ptr()
             L.bias = flat[slot.b_off:].data_ptr()
-            L.ldw, L.ntiles, L.N = sh.f_ld, sh.f_rows // 16, slot.out_dim
+            L.ks, L.ntiles, L.N = sh.f_ld // 32, sh.f_rows // 16, slot.out_dim
         else:
             assert sh.b_off >= 0
             L.W = shadow[sh.b_off:].data_ptr()
-            L.bias = None
-            L.ldw, L.ntiles, L.N = sh.b_ld, sh.b_rows // 16, sh.b_c1 - sh.b_c0
+            L.bias = self.zero_bias.data_ptr()
+            L.ks, L.ntiles, L.N = sh.b_ld // 32, sh.b_rows // 16, sh.b_c1 - sh.b_c0
         return L
 
     def _wgrad(self, triples, opt=None) -> None:

@@ -239,9 +239,12 @@ def pad32(n: int) -> int:
 class ShadowSlot:
     """bf16 copies of one weight matrix ``W[out, in]``.
 
-    forward   ``Wf[pad16(out), pad32(in)]``      — B operand of ``y = x W^T`` (K = in, contiguous)
+    forward   ``Wf[pad16(out), pad32(in)]``      — B operand of ``y = x W^T`` (K = in)
     backward  ``Wb[pad16(c1-c0), pad32(out)]``   — B operand of ``dX = dY W`` restricted to input
-                                                   columns ``[c0, c1)`` (K = out, contiguous)
+                                                   columns ``[c0, c1)`` (K = out)
+    Both are stored in MFMA fragment order (:func:`pack_fragments`): the 64 lanes x 8 elements
+    a wave feeds to ``v_mfma_f32_16x16x32_bf16`` for one (16-column tile, 32-wide K-step) are one
+    contiguous 1 KB block, so the kernels stream weights as whole cache lines.
     Offsets are in bf16 elements, 16-byte aligned; ``b_off = -1`` when no transpose is kept.
     """
     f_off: int
@@ -285,6 +288,19 @@ class ShadowLayout:
         return ShadowLayout(actor, critic, off)
 
 
+def pack_fragments(m: torch.Tensor) -> torch.Tensor:
+    """``[rows (multiple of 16), K (multiple of 32)]`` -> flat fragment order
+    ``[rows/16][K/32][(k%32)/8][row%16][k%8]`` (``packed_off`` in ``csrc/common.h``)."""
+    rows, k = m.shape
+    assert rows % 16 == 0 and k % 32 == 0
+    return m.reshape(rows // 16, 16, k // 32, 4, 8).permute(0, 2, 3, 1, 4).reshape(-1)
+
+
+def unpack_fragments(flat: torch.Tensor, rows: int, k: int) -> torch.Tensor:
+    """Inverse of :func:`pack_fragments`."""
+    return flat.reshape(rows // 16, k // 32, 4, 16, 8).permute(0, 3, 1, 2, 4).reshape(rows, k)
+
+
 def refresh_shadows(flat: torch.Tensor, shadow: torch.Tensor, lay: "LearnerLayout", sl: ShadowLayout) -> None:
     """Rebuild every bf16 shadow from the fp32 masters with torch ops (initialisation,
     checkpoint load, data-parallel broadcast; the steady state is maintained by the
@@ -294,8 +310,10 @@ def refresh_shadows(flat: torch.Tensor, shadow: torch.Tensor, lay: "LearnerLayou
         for net, slots in ((lay.actor, sl.actor), (lay.critic, sl.critic)):
             for s, sh in zip(net.layers, slots):
                 W = flat[s.w_off: s.w_off + s.w_numel].view(s.out_dim, s.ld)[:, : s.in_dim]
-                f = shadow[sh.f_off: sh.f_off + sh.f_rows * sh.f_ld].view(sh.f_rows, sh.f_ld)
+                f = torch.zeros(sh.f_rows, sh.f_ld, dtype=torch.bfloat16, device=shadow.device)
                 f[: s.out_dim, : s.in_dim] = W.to(torch.bfloat16)
+                shadow[sh.f_off: sh.f_off + sh.f_rows * sh.f_ld] = pack_fragments(f)
                 if sh.b_off >= 0:
-                    b = shadow[sh.b_off: sh.b_off + sh.b_rows * sh.b_ld].view(sh.b_rows, sh.b_ld)
+                    b = torch.zeros(sh.b_rows, sh.b_ld, dtype=torch.bfloat16, device=shadow.device)
                     b[: sh.b_c1 - sh.b_c0, : s.out_dim] = W[:, sh.b_c0: sh.b_c1].t().to(torch.bfloat16)
+                    shadow[sh.b_off: sh.b_off + sh.b_rows * sh.b_ld] = pack_fragments(b)

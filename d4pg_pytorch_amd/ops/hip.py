@@ -134,7 +134,7 @@ class NstepArgs(C.Structure):
 
 
 class LayerW(C.Structure):
-    _fields_ = [("W", vp), ("bias", vp), ("ldw", C.c_int), ("ntiles", C.c_int), ("N", C.c_int), ("pad_", C.c_int)]
+    _fields_ = [("W", vp), ("bias", vp), ("ks", C.c_int), ("ntiles", C.c_int), ("N", C.c_int), ("pad_", C.c_int)]
 
 
 class PhaseDims(C.Structure):
