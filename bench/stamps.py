@@ -52,6 +52,9 @@ def main():
         acc = rows if acc is None else [[a + b for a, b in zip(ra, rb)] for ra, rb in zip(acc, rows)]
         n += 1
     out = {}
+    out["loss_detail_last_iter"] = {"cf3_barrier_to_row0_start": (v[16] - v[9]) / 100.0, "row0_math": (v[17] - v[16]) / 100.0,
+                                    "row0_stores": (v[18] - v[17]) / 100.0, "row1_total": (v[19] - v[18]) / 100.0,
+                                    "row1_end_to_barrier": (v[10] - v[19]) / 100.0}
     for names, r, key in ((CRITIC, acc[0], "critic_phase"), (ACTOR, acc[1], "actor_phase")):
         out[key] = {nm: round(x / n, 2) for nm, x in zip(names, r)}
         out[key]["total_us"] = round(sum(r) / n, 2)

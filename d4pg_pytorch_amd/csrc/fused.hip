@@ -411,19 +411,24 @@ template <int SL, int M>
 __device__ __forceinline__ void critic_rows(const CriticPhaseArgs& a, int row0, int lane, int wave, const float* lg_t,
                                             const float* lg_o, __bf16* dlg, float* sp, float* sb, const float* rs) {
     const PhaseDims& d = a.d;
-    for (int r = wave; r < M; r += NW) {
+#pragma unroll
+    for (int r = wave; r < M; r += NW) {      // M / NW rows per wave, unrolled: independent chains interleave
         const int b = row0 + r;
         const float rew = rs[r], nd = rs[M + r], g = rs[2 * M + r], scale = rs[3 * M + r];
         if (d.distributional) {
             float lt[SL], lo[SL], m[SL], dl[SL];
+            // consecutive rows of a wave alternate between two scratch rows so that they can overlap
+            float* scratch = ((((r - wave) / NW) & 1) ? sb : sp) + wave * 256;
 #pragma unroll
             for (int s = 0; s < SL; ++s) {
                 const int j = lane + 64 * s;
                 lt[s] = j < d.NO ? lg_t[r * d.nop + j] : -INFINITY;
                 lo[s] = j < d.NO ? lg_o[r * d.nop + j] : -INFINITY;
             }
+            if (r == 0) STAMP(0, 16);
             const float loss = d4pg_critic_row<SL, true>(lt, lo, rew, nd, g, d.NO, d.v_min, d.v_max,
-                                                   d.use_ce, sp + wave * 256, sb + wave * 256, lane, m, dl);
+                                                   d.use_ce, scratch, scratch, lane, m, dl);
+            if (r == 0) STAMP(0, 17);
 #pragma unroll
             for (int s = 0; s < SL; ++s) {
                 const int j = lane + 64 * s;
@@ -437,6 +442,8 @@ __device__ __forceinline__ void critic_rows(const CriticPhaseArgs& a, int row0, 
                 a.per_loss[b] = loss;
                 a.priority[b] = fabsf(loss) + 1e-4f;
             }
+            if (r == 0) STAMP(0, 18);
+            if (r == NW) STAMP(0, 19);
         } else if (lane == 0) {
             float y = rew + nd * g * lg_t[r * d.nop];
             y = fminf(d.max_value, fmaxf(d.min_value, y));
@@ -927,6 +934,28 @@ struct WgradGroup {
     WgradAdam opt;
 };
 
+// optimiser state of one parameter, fetched at kernel entry (ahead of the stash loads and the
+// MFMA loop, so its memory latency overlaps theirs)
+struct AdamState {
+    float m, v, p, t;
+};
+__device__ __forceinline__ AdamState adam_fetch(const WgradAdam& o, long long idx) {
+    return AdamState{o.m[idx], o.v[idx], o.p[idx], o.t[idx]};
+}
+__device__ __forceinline__ float adam_apply(const WgradAdam& o, long long idx, const AdamState& s, float g,
+                                            float step_size, float inv_sqrt_bc2, float& t_out) {
+    float m = s.m, v = s.v, p = s.p;
+    m = o.beta1 * m + (1.f - o.beta1) * g;
+    v = o.beta2 * v + (1.f - o.beta2) * g * g;
+    p = p - step_size * (m / (sqrtf(v) * inv_sqrt_bc2 + o.eps));
+    o.m[idx] = m;
+    o.v[idx] = v;
+    o.p[idx] = p;
+    const float t = (1.f - o.tau) * s.t + o.tau * p;
+    o.t[idx] = t;
+    t_out = t;
+    return p;
+}
 __device__ __forceinline__ float adam_elem(const WgradAdam& o, long long idx, float g, float step_size,
                                            float inv_sqrt_bc2, float& t_out) {
     float m = o.m[idx], v = o.v[idx], p = o.p[idx];
@@ -966,6 +995,19 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGroup g) {
     const int m_c = m < d.rowsA ? m : d.rowsA - 1, n_c = n < d.rowsB ? n : d.rowsB - 1;
     const __bf16* arow = d.AT + (size_t)m_c * g.Bp + 8 * h;
     const __bf16* brow = d.BT + (size_t)n_c * g.Bp + 8 * h;
+    // fused optimiser: this thread finishes rows pm0 .. pm0+3 of column pn of the tile
+    const WgradAdam& o = g.opt;
+    const bool fuse = o.p != nullptr;
+    const int pm0 = tm * 32 + 8 * wave + 4 * h, pn = tn * 32 + r;
+    AdamState ast[4];
+    float step_size = 0.f, inv_sqrt_bc2 = 0.f;
+    if (fuse) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (pm0 + i < d.M && pn < d.N) ast[i] = adam_fetch(o, d.w_off + (long long)(pm0 + i) * d.ldc + pn);
+        step_size = o.st->bc1;
+        inv_sqrt_bc2 = o.st->bc2;
+    }
     const int ksteps = g.Bp >> 4;              // k-steps of 16
     const int per = (ksteps + 3) >> 2;
     const int k0 = wave * per, k1 = min(ksteps, k0 + per);
@@ -991,12 +1033,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGroup g) {
         if (lane < 32) cs[wave * 32 + lane] = asum;
     }
     __syncthreads();
-    const WgradAdam& o = g.opt;
-    const bool fuse = o.p != nullptr;
-    float step_size = 0.f, inv_sqrt_bc2 = 0.f;
     if (fuse) {
-        step_size = o.lr / o.st->bc1;
-        inv_sqrt_bc2 = 1.f / sqrtf(o.st->bc2);
+        step_size = o.lr / step_size;
+        inv_sqrt_bc2 = 1.f / sqrtf(inv_sqrt_bc2);
     }
     const int wv = threadIdx.x >> 6;
     const int cn = tn * 32 + r;
@@ -1012,7 +1051,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGroup g) {
             d.C[(size_t)cm * d.ldc + cn] = gv;
             if (fuse) {
                 float tv;
-                const float pv = adam_elem(o, d.w_off + (long long)cm * d.ldc + cn, gv, step_size, inv_sqrt_bc2, tv);
+                const float pv = adam_apply(o, d.w_off + (long long)cm * d.ldc + cn, ast[i], gv, step_size,
+                                            inv_sqrt_bc2, tv);
                 pnew[i] = pv;
                 if (d.sf_off >= 0) {
                     const long long so = d.sf_off + packed_off(cm, cn, d.sf_ld >> 5);

@@ -8,6 +8,19 @@
 // runs on one wave and is bound by instruction issue, where the IEEE-exact library
 // expansions of division and log cost 10-60 instructions each.
 // FAST = false keeps the IEEE-exact forms (the fp32 pipeline tracks eager PyTorch to 2e-5).
+// Ordering point between LDS accesses of different lanes of ONE wave to the wave's private
+// scratch row.  The hardware executes a wave's LDS instructions in program order, and the
+// compiler keeps may-aliasing accesses in program order, so nothing needs to be emitted;
+// the exact build keeps explicit wave-level fences, the fast build leaves the scheduler
+// free to interleave the independent rows a wave processes.
+template <bool FAST>
+__device__ __forceinline__ void lds_order() {
+    if constexpr (!FAST) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
 template <bool FAST>
 __device__ __forceinline__ float rcp_(float x) {
     if constexpr (FAST) return __builtin_amdgcn_rcpf(x);
@@ -65,8 +78,7 @@ __device__ __forceinline__ float d4pg_critic_row(float (&lt)[SLOTS], float (&lo)
         const int j = lane + 64 * s;
         if (j < N) sp[j] = 0.f;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    lds_order<FAST>();
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
         const int j = lane + 64 * s;
@@ -85,16 +97,13 @@ __device__ __forceinline__ float d4pg_critic_row(float (&lt)[SLOTS], float (&lo)
             __hip_atomic_fetch_add(&sp[ui], pj * fr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    lds_order<FAST>();
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
         const int i = lane + 64 * s;
         m[s] = i < N ? sp[i] : 0.f;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    lds_order<FAST>();
 
     float q[SLOTS], gi[SLOTS];
     float loss = 0.f, gq = 0.f, msum = 0.f;
