@@ -19,6 +19,7 @@ from .base import BoxSpace, VecEnv
 from .gym_adapter import GymVec, gym_available
 from .pendulum import PendulumVec
 from .synthetic import CartPoleContinuousVec, SyntheticVec
+from .wrappers import BipedalWalker, EnvWrapper, LunarLanderContinous, PendulumWrapper  # noqa: E402,F401
 
 REWARD_SCALE = {"Pendulum-v0": 100.0, "Pendulum-v1": 100.0, "LunarLanderContinuous-v2": 100.0}
 
@@ -47,4 +48,5 @@ def create_env_wrapper(config, num_envs=None, seed=None) -> VecEnv:
 
 
 __all__ = ["create_env_wrapper", "VecEnv", "BoxSpace", "PendulumVec", "SyntheticVec",
-           "CartPoleContinuousVec", "GymVec", "gym_available"]
+           "CartPoleContinuousVec", "GymVec", "gym_available",
+           "EnvWrapper", "PendulumWrapper", "LunarLanderContinous", "BipedalWalker"]

@@ -55,33 +55,54 @@ def test_gpu_actor_matches_cpu_actor():
     assert set(gpu.state_dict()) == set(cpu.state_dict())
 
 
-def test_data_parallel_wiring_on_one_gpu():
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_data_parallel_wiring_on_one_gpu(dtype):
     """world=1 NCCL(RCCL) group on the single GPU: the segmented-graph path with the
-    all-reduce between segments must reproduce the fused single-graph path."""
-    import torch.distributed as dist
-    from d4pg_pytorch_amd.models.hip_core import HipCore
+    all-reduce between segments must reproduce the fused single-graph path (for bf16 that
+    also pits the stand-alone Adam/Polyak/shadow kernel against the one fused into wgrad)."""
+    from d4pg_pytorch_amd.models.core import build_core
     from d4pg_pytorch_amd.parallel.comm import TorchDistComm
     from d4pg_pytorch_amd.replay.hbm_replay import HbmReplay
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29800 + os.getpid() % 100), RANK="0", WORLD_SIZE="1")
+    port = 29800 + os.getpid() % 100 + (100 if dtype == "bf16" else 0)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
     comm = TorchDistComm(device=torch.device("cuda", 0), rank=0, world=1)
     try:
         cfg = default_config(env="Walker2d-v2", model="d4pg", batch_size=256, device="cuda", v_min=0.0, v_max=50.0,
-                             replay_mem_size=50_000, num_steps_train=100)
+                             replay_mem_size=50_000, num_steps_train=100, compute_dtype=dtype)
         rows = torch.randn(10_000, 44, device="cuda")
         rows[:, 17 + 6 + 1] = 0.0
         rows[:, 17 + 6 + 2] = 0.95
-        outs = []
+        outs = {1: [], 10: []}
         for use_sync in (False, True):
-            core = HipCore(cfg, "cuda")
+            core = build_core(cfg, "cuda")
             rp = HbmReplay(cfg, "cuda", core.dev_state)
             core.attach_replay(rp)
             rp.insert(rows)
             if use_sync:
                 core.grad_sync = lambda g: comm.all_reduce_sum_(g)    # forces the 3-graph path
-            for _ in range(10):
+            for it in range(1, 11):
                 core.update_from_replay()
-            torch.cuda.synchronize()
-            outs.append(core.online.flat.clone())
-        torch.testing.assert_close(outs[0], outs[1], rtol=0, atol=0)
+                if it in outs:
+                    torch.cuda.synchronize()
+                    outs[it].append((core.online.flat.clone(), core.target.flat.clone()))
+            if dtype == "bf16":
+                # the shadows kept by the stand-alone optimiser kernel == a rebuild from the masters
+                from d4pg_pytorch_amd.models.nets import refresh_shadows
+                want = torch.zeros_like(core.shadow_online)
+                refresh_shadows(core.online.flat.detach(), want, core.layout, core.sl)
+                assert torch.equal(core.shadow_online, want)
+        if dtype == "fp32":
+            # the same kernels run in both modes -> bit-identical
+            for it in (1, 10):
+                torch.testing.assert_close(outs[it][0][0], outs[it][1][0], rtol=0, atol=0)
+                torch.testing.assert_close(outs[it][0][1], outs[it][1][1], rtol=0, atol=0)
+        else:
+            # the optimiser runs in two different kernels (fused into wgrad / stand-alone) whose
+            # multiply-add contraction may differ in the last bit: one update agrees to an ulp;
+            # later the bf16 rounding of the weights amplifies that into Adam-step-sized differences
+            torch.testing.assert_close(outs[1][0][0], outs[1][1][0], rtol=0, atol=1e-7)
+            torch.testing.assert_close(outs[1][0][1], outs[1][1][1], rtol=0, atol=1e-7)
+            diff = (outs[10][0][0] - outs[10][1][0]).abs()
+            assert diff.max().item() < 10 * 5e-4 and diff.mean().item() < 5e-5
     finally:
         comm.close()
