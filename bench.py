@@ -12,9 +12,23 @@ with synthetic transitions of the environment's observation/action shape.
 
 Configurations (the ones BASELINE.json names):
   N == 1 : LunarLanderContinuous-v2 D4PG, batch 256, n-step 5, 51 atoms, 400-wide MLPs
-  N  > 1 : Walker2d-v2 D4PG, data-parallel learners, batch 256 per rank (weak scaling),
-           gradients all-reduced over RCCL before each Adam step
+  N  > 1 : Walker2d-v2 D4PG, data-parallel learners over RCCL, batch 256 per rank (weak
+           scaling: every rank draws 256 rows per update from its own HBM replay shard;
+           one synchronous update consumes the global batch of N x 256 rows)
 Other shapes: --env Ant-v2 --batch 4096 --model d3pg --per ...
+
+Data-parallel modes (``--dp-mode``, N > 1):
+  replicated      the sampled rows are all-gathered (one ~20 KB/rank collective, one update
+                  ahead on a side stream) and every rank runs the update on the global
+                  batch as ONE graph; no gradient traffic.  A learner update is latency
+                  bound, not throughput bound (81.6 us at batch 256, 92 us at 1024, 119 us at
+                  2048 on one MI355X), so replicating the arithmetic is cheaper than two
+                  latency-bound gradient all-reduces on the critical path.
+  grad_allreduce  every rank runs the update on its 256 rows and the critic and actor
+                  gradient buckets (0.7-0.9 MB each) are all-reduced before each Adam step.
+  both (default)  times the two back to back; ``value`` is the replicated mode, the other
+                  is reported as ``grad_allreduce_value``.
+Both make the update a single learner would make on the concatenated global batch.
 
 For N > 1 the driver launches this file under torch.distributed.run (one rank
 per GPU).  Rank 0 prints ONE JSON line.  ``value`` aggregates all ranks:
@@ -52,6 +66,11 @@ def parse_args():
     ap.add_argument("--baseline", action="store_true",
                     help="time the unfused eager-PyTorch update (reference op sequence) instead")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--dp-mode", default="both", choices=["both", "replicated", "grad_allreduce"],
+                    help="data-parallel scheme for N > 1 (see the module docstring)")
+    ap.add_argument("--dp-selftest", action="store_true",
+                    help="with one GPU: run the N > 1 code path (both data-parallel modes) over a world-size-1 "
+                         "RCCL group, to check the wiring on a single-GPU box")
     return ap.parse_args()
 
 
@@ -85,7 +104,12 @@ def main() -> None:
 
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    comm = TorchDistComm(device=device) if world > 1 else LocalComm()
+    if world == 1 and args.dp_selftest:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
+        comm = TorchDistComm(device=device, rank=0, world=1)
+    else:
+        comm = TorchDistComm(device=device) if world > 1 else LocalComm()
 
     env = args.env
     if env == "auto":
@@ -102,10 +126,32 @@ def main() -> None:
     S, A = cfg["state_dim"], cfg["action_dim"]
     gamma_n = cfg["discount_rate"] ** cfg["n_step_returns"]
 
+    def fill(replay):
+        n_fill = min(args.prefill, args.replay_size)
+        chunk = 50_000
+        for off in range(0, n_fill, chunk):
+            n = min(chunk, n_fill - off)
+            replay.insert(synthetic_rows(n, S, A, replay.row_ld, gamma_n, device, seed=1000 * (rank + 1) + off))
+
+    def timed(one_step):
+        for _ in range(args.warmup):
+            one_step()
+        comm.barrier()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step()
+        comm.barrier()
+        torch.cuda.synchronize(device)
+        return comm.all_reduce_max_scalar(time.perf_counter() - t0)
+
+    extra = {}
+    dp_mode = "none"
     if args.baseline:
         from d4pg_pytorch_amd.models.core import Batch, TorchCore
         core = TorchCore(cfg, device)
         attach_data_parallel(core, comm)
+        dp_mode = "grad_allreduce" if world > 1 else "none"
         rows = synthetic_rows(args.prefill, S, A, 2 * S + A + 3, gamma_n, device, seed=rank + 1)
 
         def one_step():
@@ -115,31 +161,46 @@ def main() -> None:
             b = Batch(r[:, :S], r[:, S:S + A], r[:, S + A], r[:, S + A + 3:S + A + 3 + S], r[:, S + A + 1],
                       r[:, S + A + 2], None, idx)
             core.update(b)
+        dt = timed(one_step)
     else:
         from d4pg_pytorch_amd.models.core import build_core
+        from d4pg_pytorch_amd.parallel.replicated import attach_replicated
         from d4pg_pytorch_amd.replay.hbm_replay import HbmReplay
-        core = build_core(cfg, device)
-        replay = HbmReplay(cfg, device, core.dev_state)
-        core.attach_replay(replay)
-        attach_data_parallel(core, comm)
-        n_fill = min(args.prefill, args.replay_size)
-        chunk = 50_000
-        for off in range(0, n_fill, chunk):
-            n = min(chunk, n_fill - off)
-            replay.insert(synthetic_rows(n, S, A, replay.row_ld, gamma_n, device, seed=1000 * (rank + 1) + off))
-        one_step = core.update_from_replay
 
-    for _ in range(args.warmup):
-        one_step()
-    comm.barrier()
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    comm.barrier()
-    torch.cuda.synchronize(device)
-    dt = time.perf_counter() - t0
-    dt = comm.all_reduce_max_scalar(dt)
+        def run_grad_allreduce():
+            core = build_core(cfg, device)
+            replay = HbmReplay(cfg, device, core.dev_state)
+            core.attach_replay(replay)
+            attach_data_parallel(core, comm)
+            fill(replay)
+            return core, timed(core.update_from_replay)
+
+        def run_replicated():
+            core = build_core(dict(cfg, batch_size=args.batch * world), device)
+            replay = HbmReplay(cfg, device, core.dev_state)
+            fill(replay)
+            dp = attach_replicated(core, replay, comm, args.batch)
+            t = timed(dp.update)
+            drift = dp.check_consistency()
+            assert drift == 0.0, f"learner replicas diverged (checksum difference {drift})"
+            return core, t
+
+        if world == 1 and not args.dp_selftest:
+            core, dt = run_grad_allreduce()
+        elif args.dp_mode == "grad_allreduce":
+            dp_mode = "grad_allreduce"
+            core, dt = run_grad_allreduce()
+        else:
+            dp_mode = "replicated"
+            if args.dp_mode == "both":
+                try:
+                    _, dt_ar = run_grad_allreduce()
+                    extra["grad_allreduce_value"] = round(args.steps / dt_ar * world, 2)
+                    extra["grad_allreduce_ms_per_step"] = round(1000.0 * dt_ar / args.steps, 5)
+                except Exception as exc:      # the headline mode must still be measured
+                    extra["grad_allreduce_error"] = repr(exc)[:200]
+                torch.cuda.empty_cache()
+            core, dt = run_replicated()
 
     metrics = core.read_metrics()
     finite = all(map(lambda v: v == v and abs(v) != float("inf"), (metrics["value_loss"], metrics["policy_loss"])))
@@ -172,8 +233,11 @@ def main() -> None:
                            env, args.model.upper(), S, A, ", 51 atoms" if args.model == "d4pg" else ""),
                        "global_batch": args.batch * world, "seq_len": 1,
                        "n_step": 5, "replay": "per-hbm-sumtree" if args.per else "uniform-hbm",
-                       "parallelism": "dp%d" % world},
+                       "parallelism": "dp%d" % world + {
+                           "none": "", "replicated": " (sharded HBM replay, all-gathered batches, replicated update)",
+                           "grad_allreduce": " (gradient all-reduce)"}[dp_mode]},
         }
+        out.update(extra)
         print(json.dumps(out), flush=True)
     comm.close()
 

@@ -178,53 +178,65 @@ struct SampleArgs {
     long long total_steps;
 };
 
+// Draw the replay slot of sample `b` of `B` (all 64 lanes of the wave take part and get the
+// same result): uniform, or stratified proportional through the fan-out-64 tree with the
+// importance weight (p_min / p_leaf)^beta.  `step` selects the RNG stream position and the
+// point on the beta schedule.
+__device__ __forceinline__ long long draw_slot(const TreeDesc& t, int prioritized, int b, int B, long long step,
+                                               long long size, unsigned long long seed, float per_b0, float per_b1,
+                                               long long total_steps, int lane, float& w) {
+    uint32_t rnd[4];
+    philox4x32((uint32_t)b, (uint32_t)step, (uint32_t)(step >> 32), 0x5EEDu, (uint32_t)seed, (uint32_t)(seed >> 32),
+               rnd);
+    const double u = u01_from_bits(rnd[0], rnd[1]);
+    long long slot;
+    w = 1.f;
+    if (!prioritized) {
+        slot = (long long)(u * (double)size);
+        if (slot >= size) slot = size - 1;
+        return slot;
+    }
+    // root totals from the top level
+    const double top = tree_load_sum(t, t.L, lane);
+    const double total = wave_sum_d(top);
+    const float pmin = wave_min(tree_load_min(t, t.L, lane));
+    double target = ((double)b + u) * (total / (double)B);
+    long long g = 0;
+    float pleaf = 0.f;
+    for (int l = t.L; l >= 0; --l) {
+        const long long c = g * 64 + lane;
+        const double v = tree_load_sum(t, l, c);
+        const double incl = wave_scan_incl_d(v, lane);
+        const unsigned long long live = __ballot(v > 0.0);
+        const unsigned long long hit = __ballot(v > 0.0 && incl > target);
+        int pick;
+        if (hit) pick = __ffsll((long long)hit) - 1;
+        else if (live) pick = 63 - __clzll((long long)live);   // rounding pushed target past the end
+        else pick = 0;
+        const double excl = __shfl(incl - v, pick, 64);
+        target -= excl;
+        if (target < 0.0) target = 0.0;
+        g = g * 64 + pick;
+        if (l == 0) pleaf = (float)__shfl(v, pick, 64);
+    }
+    slot = g < size ? g : size - 1;
+    // beta schedule evaluated locally (per_beta in DevState belongs to the tick)
+    double frac = (double)step / (double)(total_steps > 0 ? total_steps : 1);
+    frac = frac > 1.0 ? 1.0 : frac;
+    const float beta = (float)(per_b0 + frac * (per_b1 - per_b0));
+    w = (pleaf > 0.f && pmin < INFINITY) ? powf(pmin / pleaf, beta) : 1.f;
+    return slot;
+}
+
 __global__ __launch_bounds__(256) void replay_sample_kernel(const SampleArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.x * 4 + wave;
     const long long step = a.st->step_done;
     const long long size = a.st->replay_size;
     if (b < a.B && size > 0) {
-        uint32_t rnd[4];
-        philox4x32((uint32_t)b, (uint32_t)step, (uint32_t)(step >> 32), 0x5EEDu,
-                   (uint32_t)a.st->seed, (uint32_t)(a.st->seed >> 32), rnd);
-        const double u = u01_from_bits(rnd[0], rnd[1]);
-        long long slot;
-        float w = 1.f;
-        if (!a.prioritized) {
-            slot = (long long)(u * (double)size);
-            if (slot >= size) slot = size - 1;
-        } else {
-            const TreeDesc& t = a.t;
-            // root totals from the top level
-            const double top = tree_load_sum(t, t.L, lane);
-            const double total = wave_sum_d(top);
-            const float pmin = wave_min(tree_load_min(t, t.L, lane));
-            double target = ((double)b + u) * (total / (double)a.B);
-            long long g = 0;
-            float pleaf = 0.f;
-            for (int l = t.L; l >= 0; --l) {
-                const long long c = g * 64 + lane;
-                const double v = tree_load_sum(t, l, c);
-                const double incl = wave_scan_incl_d(v, lane);
-                const unsigned long long live = __ballot(v > 0.0);
-                const unsigned long long hit = __ballot(v > 0.0 && incl > target);
-                int pick;
-                if (hit) pick = __ffsll((long long)hit) - 1;
-                else if (live) pick = 63 - __clzll((long long)live);   // rounding pushed target past the end
-                else pick = 0;
-                const double excl = __shfl(incl - v, pick, 64);
-                target -= excl;
-                if (target < 0.0) target = 0.0;
-                g = g * 64 + pick;
-                if (l == 0) pleaf = (float)__shfl(v, pick, 64);
-            }
-            slot = g < size ? g : size - 1;
-            // beta schedule evaluated locally (per_beta in DevState belongs to the tick)
-            double frac = (double)step / (double)(a.total_steps > 0 ? a.total_steps : 1);
-            frac = frac > 1.0 ? 1.0 : frac;
-            const float beta = (float)(a.per_b0 + frac * (a.per_b1 - a.per_b0));
-            w = (pleaf > 0.f && pmin < INFINITY) ? powf(pmin / pleaf, beta) : 1.f;
-        }
+        float w;
+        const long long slot = draw_slot(a.t, a.prioritized, b, a.B, step, size, a.st->seed, a.per_b0, a.per_b1,
+                                         a.total_steps, lane, w);
         // ---- gather the row ----
         const float* row = a.rp.rows + slot * a.rp.row_ld;
         const int S = a.rp.S, A = a.rp.A;
@@ -254,6 +266,128 @@ D4PG_API int d4pg_replay_sample(const SampleArgs* a, hipStream_t stream) {
     hipLaunchKernelGGL(replay_sample_kernel, dim3((a->B + 3) / 4), dim3(256), 0, stream, *a);
     return (int)hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------
+// Packed batches (replicated data parallelism, parallel/replicated.py): every learner rank
+// draws its share of the next K global batches (a "chunk") from its own replay shard into ONE
+// contiguous buffer  chunk[K][B][row_ld + PACK_EXTRA]
+//     row: [ replay row (row_ld floats) | IS weight | slot bits 31..0 | slot bits 63..32 | 0 ]
+// which is all-gathered across the ranks as is ([world][K][B][..]); batch_unpack then spreads
+// the rows of the batch that belongs to the update in flight over the learner's input
+// buffers (and performs the per-update tick).
+constexpr int PACK_EXTRA = 4;     // floats appended to a replay row
+
+struct SampleRowsArgs {
+    ReplayDesc rp;
+    TreeDesc t;
+    DevState* st;
+    float* out;          // [K * B, row_ld + PACK_EXTRA]
+    int B;               // rows per batch (the strata of a prioritised draw)
+    int K;               // batches in the chunk
+    int prioritized;
+    int pad_;
+    long long step;      // update that consumes batch 0 of the chunk; batch j belongs to step + j (RNG
+                         // stream position and beta schedule).  The chunk is drawn ahead of time, so
+                         // the device step counter is not used.
+    float per_b0, per_b1;
+    long long total_steps;
+};
+
+__global__ __launch_bounds__(256) void replay_sample_rows_kernel(const SampleRowsArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wave;
+    const long long size = a.st->replay_size;
+    if (b >= a.B * a.K || size <= 0) return;
+    const int j = b / a.B, i = b - j * a.B;
+    float w;
+    const long long slot = draw_slot(a.t, a.prioritized, i, a.B, a.step + j, size, a.st->seed, a.per_b0, a.per_b1,
+                                     a.total_steps, lane, w);
+    const int ld = a.rp.row_ld;
+    const float* row = a.rp.rows + slot * ld;
+    float* o = a.out + (size_t)b * (ld + PACK_EXTRA);
+    for (int c = lane; c < ld; c += 64) o[c] = row[c];
+    if (lane == 0) {
+        o[ld] = w;
+        o[ld + 1] = __int_as_float((int)(slot & 0xFFFFFFFFll));
+        o[ld + 2] = __int_as_float((int)(slot >> 32));
+        o[ld + 3] = 0.f;
+    }
+}
+
+D4PG_API int d4pg_replay_sample_rows(const SampleRowsArgs* a, hipStream_t stream) {
+    if (a->B < 1 || a->K < 1 || a->out == nullptr) return -1;
+    if (a->prioritized && (a->t.L < 0 || a->t.L > MAXL || a->t.n[a->t.L] > 64)) return -2;
+    hipLaunchKernelGGL(replay_sample_rows_kernel, dim3((a->B * a->K + 3) / 4), dim3(256), 0, stream, *a);
+    return (int)hipGetLastError();
+}
+
+// The chunk a batch is taken from, and the batch inside it, follow from the device step
+// counter: s = step_done - step0, batch j = s % K of buffer (s / K) & 1.  The launch is
+// therefore the same for every update and is captured with the rest of the update graph.
+struct UnpackArgs {
+    const float* in0;    // gathered chunk, even chunks  [world][K][Bl][row_ld + PACK_EXTRA]
+    const float* in1;    // gathered chunk, odd chunks
+    DevState* st;
+    float* sa;
+    float* s_pi;
+    float* s2_a2;
+    float* reward;
+    float* done;
+    float* gamma;
+    float* weights;
+    long long* idx;
+    int B;               // global batch = world * Bl
+    int Bl;              // rows per rank and batch
+    int K;               // batches per chunk
+    int S, A, row_ld, ld_x;
+    int do_tick;
+    long long step0;     // value of the device step counter at the first batch of chunk 0
+    float beta1, beta2, per_b0, per_b1;
+    long long total_steps;
+};
+
+__global__ __launch_bounds__(256) void batch_unpack_kernel(const UnpackArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wave;
+    if (b < a.B) {
+        const long long s = a.st->step_done - a.step0;
+        const int j = (int)(s % a.K);
+        const float* base = ((s / a.K) & 1) ? a.in1 : a.in0;
+        const int r = b / a.Bl, i = b - r * a.Bl;
+        const float* row = base + ((size_t)(r * a.K + j) * a.Bl + i) * (a.row_ld + PACK_EXTRA);
+        const int S = a.S, A = a.A;
+        const size_t ob = (size_t)b * a.ld_x;
+        for (int c = lane; c < S; c += 64) {
+            const float sv = row[c];
+            a.sa[ob + c] = sv;
+            a.s_pi[ob + c] = sv;
+            a.s2_a2[ob + c] = row[S + A + 3 + c];
+        }
+        for (int c = lane; c < A; c += 64) a.sa[ob + S + c] = row[S + c];
+        if (lane == 0) {
+            a.reward[b] = row[S + A];
+            a.done[b] = row[S + A + 1];
+            a.gamma[b] = row[S + A + 2];
+            a.weights[b] = row[a.row_ld];
+            const unsigned int lo = (unsigned int)__float_as_int(row[a.row_ld + 1]);
+            const unsigned int hi = (unsigned int)__float_as_int(row[a.row_ld + 2]);
+            a.idx[b] = (long long)(((unsigned long long)hi << 32) | lo);
+        }
+    }
+    // the tick reads step_done (as every block above does) and writes step_cur / bc1 / bc2 / per_beta,
+    // which nothing in this kernel reads
+    if (a.do_tick && blockIdx.x == 0 && threadIdx.x == 0)
+        devstate_tick(a.st, a.beta1, a.beta2, a.per_b0, a.per_b1, a.total_steps);
+}
+
+D4PG_API int d4pg_batch_unpack(const UnpackArgs* a, hipStream_t stream) {
+    if (a->B < 1 || a->Bl < 1 || a->K < 1 || a->B % a->Bl) return -1;
+    if (a->ld_x < a->S + a->A || a->row_ld < 2 * a->S + a->A + 3 || a->in0 == nullptr || a->in1 == nullptr) return -2;
+    hipLaunchKernelGGL(batch_unpack_kernel, dim3((a->B + 3) / 4), dim3(256), 0, stream, *a);
+    return (int)hipGetLastError();
+}
+
+D4PG_API int d4pg_pack_extra() { return PACK_EXTRA; }
 
 // ---------------------------------------------------------------------------
 // Load an externally provided batch (host sampler / tests) into the learner's

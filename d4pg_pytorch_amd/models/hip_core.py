@@ -81,6 +81,8 @@ class HipCore(CoreBase):
         self._graphs: Dict[str, List] = {}
         self._segments_cache: Dict[str, List[Callable[[], None]]] = {}
         self._side = torch.cuda.Stream(device=dev)
+        self.packed_unpack: Dict[str, H.UnpackArgs] = {}     # batch sources registered by register_packed()
+        self.packed_prio = None
 
     # ------------------------------------------------------------------ state
     def _write_dev_state(self, step: int, seed: Optional[int] = None, keep_replay: bool = False) -> None:
@@ -176,9 +178,11 @@ class HipCore(CoreBase):
         def seg_critic() -> None:
             if source == "replay":
                 self.replay.enqueue_sample(self, do_tick=True)
-            else:
+            elif source == "external":
                 H._check(H.lib().d4pg_tick(st, b1, b2, cfg["priority_beta_start"], cfg["priority_beta_end"],
                                            int(cfg["num_steps_train"]), H.stream_ptr()), "d4pg_tick")
+            else:       # a registered packed batch buffer: unpack it (this also ticks)
+                H.launch("d4pg_batch_unpack", self.packed_unpack[source])
             # layers 1..3 of target actor(s'), actor(s), critic(s,a)
             H.gemm_group([self._fwd(self.s2a2, ldx, T, a_on[0], self.h1_ta, ldh, R),
                           self._fwd(self.s_pi, ldx, P, a_on[0], self.h1_a, ldh, R),
@@ -219,13 +223,17 @@ class HipCore(CoreBase):
                 H.launch("d3pg_critic_loss", la)
             # PER write-back runs on a forked branch, joined at the end of the segment
             forked = None
-            if source == "replay" and self.replay.prioritized:
+            packed_prio = self.packed_prio if source in self.packed_unpack else None
+            if (source == "replay" and self.replay.prioritized) or packed_prio is not None:
                 main = torch.cuda.current_stream()
                 ev = torch.cuda.Event()
                 ev.record(main)
                 self._side.wait_event(ev)
                 with torch.cuda.stream(self._side):
-                    self.replay.enqueue_priority_update(self.idx, self.prio, self.B)
+                    if packed_prio is not None:
+                        H.launch("d4pg_tree_update", packed_prio)      # this rank's rows of the global batch
+                    else:
+                        self.replay.enqueue_priority_update(self.idx, self.prio, self.B)
                     forked = torch.cuda.Event()
                     forked.record(self._side)
             # critic backward
@@ -383,6 +391,58 @@ class HipCore(CoreBase):
         self._run("external")
         self.step += 1
         return self.prio
+
+    def unpack_args(self, chunk0: torch.Tensor, chunk1: torch.Tensor, row_ld: int, local_batch: int,
+                    chunk: int) -> H.UnpackArgs:
+        """Launch descriptor that spreads one batch out of the gathered chunk buffers
+        (``[world][chunk][local_batch][row_ld + 4]``, ``HbmReplay.enqueue_sample_rows`` rows) over
+        the static input buffers and advances the device step.  Which chunk buffer and which
+        batch follow from the device step counter, counted from the learner's current step."""
+        need = self.B * chunk * (row_ld + H.PACK_EXTRA)
+        for t in (chunk0, chunk1):
+            assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == need, "chunk buffer size"
+        assert self.B % local_batch == 0
+        cfg = self.cfg
+        a = H.UnpackArgs()
+        a.in0, a.in1, a.st = chunk0.data_ptr(), chunk1.data_ptr(), self.dev_state.data_ptr()
+        a.sa, a.s_pi, a.s2_a2 = self.sa.data_ptr(), self.s_pi.data_ptr(), self.s2a2.data_ptr()
+        a.reward, a.done, a.gamma = self.reward.data_ptr(), self.done.data_ptr(), self.gamma.data_ptr()
+        a.weights, a.idx = self.weights.data_ptr(), self.idx.data_ptr()
+        a.B, a.Bl, a.K = self.B, int(local_batch), int(chunk)
+        a.S, a.A, a.row_ld, a.ld_x = self.S, self.A, int(row_ld), self.ldx
+        a.do_tick = 1
+        a.step0 = int(self.step)
+        a.beta1, a.beta2 = float(cfg["adam_beta1"]), float(cfg["adam_beta2"])
+        a.per_b0, a.per_b1 = float(cfg["priority_beta_start"]), float(cfg["priority_beta_end"])
+        a.total_steps = int(cfg["num_steps_train"])
+        return a
+
+    def register_packed(self, name: str, chunk0: torch.Tensor, chunk1: torch.Tensor, row_ld: int,
+                        local_batch: int, chunk: int = 1, prio_args=None) -> None:
+        """Make the gathered chunk buffers a batch source called ``name``: the unpack of the batch
+        that belongs to the update in flight (and, with ``prio_args``, the priority write-back of
+        this rank's rows) become part of the captured update, so ``update_from_source(name)`` is
+        a single graph replay."""
+        self.packed_unpack[name] = self.unpack_args(chunk0, chunk1, row_ld, local_batch, chunk)
+        self.packed_prio = prio_args
+        self._graphs = {k: v for k, v in self._graphs.items() if not k.startswith(name)}
+        self._segments_cache = {k: v for k, v in self._segments_cache.items() if not k.startswith(name)}
+
+    def update_from_source(self, name: str) -> torch.Tensor:
+        """One update on the registered packed batch source ``name``; returns the priorities."""
+        self._run(name)
+        self.step += 1
+        return self.prio
+
+    def update_from_packed(self, packed: torch.Tensor, row_ld: int) -> torch.Tensor:
+        """One update on an arbitrary packed batch ``[B, row_ld + 4]`` (the rows are copied into a
+        registered one-batch staging buffer first)."""
+        if getattr(self, "_packed_stage", None) is None or self._packed_stage.shape != packed.shape:
+            self._packed_stage = torch.zeros_like(packed)
+            # a one-batch "chunk": the step arithmetic of the unpack always selects batch 0
+            self.register_packed("packed", self._packed_stage, self._packed_stage, row_ld, self.B, 1, None)
+        self._packed_stage.copy_(packed)
+        return self.update_from_source("packed")
 
     def update_from_replay(self) -> torch.Tensor:
         """One update whose batch is sampled on the device from the attached replay."""

@@ -194,9 +194,11 @@ class HipCoreBf16(HipCore):
         def seg_critic() -> None:
             if source == "replay":
                 self.replay.enqueue_sample(self, do_tick=True)
-            else:
+            elif source == "external":
                 H._check(H.lib().d4pg_tick(st, b1, b2, cfg["priority_beta_start"], cfg["priority_beta_end"],
                                            int(cfg["num_steps_train"]), H.stream_ptr()), "d4pg_tick")
+            else:       # a registered packed batch buffer: unpack it (this also ticks)
+                H.launch("d4pg_batch_unpack", self.packed_unpack[source])
             a = H.CriticPhaseArgs()
             a.d = dims
             a.sa, a.s2 = self.sa.data_ptr(), self.s2a2.data_ptr()
@@ -213,13 +215,17 @@ class HipCoreBf16(HipCore):
             a.per_loss, a.priority = self.per_loss.data_ptr(), self.prio.data_ptr()
             H._check(H.lib().d4pg_critic_phase(a, self.mt, H.stream_ptr()), "d4pg_critic_phase")
             forked = None
-            if source == "replay" and self.replay.prioritized:
+            packed_prio = self.packed_prio if source in self.packed_unpack else None
+            if (source == "replay" and self.replay.prioritized) or packed_prio is not None:
                 main = torch.cuda.current_stream()
                 ev = torch.cuda.Event()
                 ev.record(main)
                 self._side.wait_event(ev)
                 with torch.cuda.stream(self._side):
-                    self.replay.enqueue_priority_update(self.idx, self.prio, self.B)
+                    if packed_prio is not None:
+                        H.launch("d4pg_tree_update", packed_prio)      # this rank's rows of the global batch
+                    else:
+                        self.replay.enqueue_priority_update(self.idx, self.prio, self.B)
                     forked = torch.cuda.Event()
                     forked.record(self._side)
             self._wgrad([(self.c_dlT, self.c_h2T, cl[2], sl.critic[2]), (self.c_dh2T, self.c_h1T, cl[1], sl.critic[1]),

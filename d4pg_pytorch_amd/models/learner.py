@@ -86,11 +86,16 @@ class Learner:
         self.device = torch.device(device if device is not None else config["device"])
         self.log_dir = log_dir
         self.num_train_steps = int(config["num_steps_train"])
-        self.core = build_core(config, self.device, seed=config["random_seed"])
+        # replicated data parallelism: every rank runs the update on the global batch
+        self.replicated = (self.comm.world > 1 and config.get("dp_mode", "replicated") == "replicated"
+                           and self.device.type == "cuda" and config.get("fused_learner", "auto") != "torch")
+        core_cfg = dict(config, batch_size=int(config["batch_size"]) * self.comm.world) if self.replicated else config
+        self.core = build_core(core_cfg, self.device, seed=config["random_seed"])
         if config.get("resume"):
             self.core.load_state_bundle(load_learner_bundle(config["resume"]))
             print(f"[learner {rank}] resumed from {config['resume']} at step {self.core.step}", flush=True)
-        attach_data_parallel(self.core, self.comm)
+        if not self.replicated:
+            attach_data_parallel(self.core, self.comm)
         self.logger = Logger(os.path.join(log_dir, "learner"), config.get("log_backend", "tb")) \
             if (log_dir and rank == 0) else None
         self.timing_tag = "learner/learner_update_timing" if config["model"] == "d4pg" else "learner/update_time"
@@ -177,7 +182,12 @@ class Learner:
         from ..replay.hbm_replay import HbmReplay
         cfg, core, ctrl = self.config, self.core, self.ctrl
         replay = HbmReplay(cfg, self.device, core.dev_state)
-        core.attach_replay(replay)
+        dp = None
+        if self.replicated:
+            from ..parallel.replicated import attach_replicated
+            dp = attach_replicated(core, replay, self.comm, int(cfg["batch_size"]))
+        else:
+            core.attach_replay(replay)
         self.replay = replay
         ingest = RingIngestor(rings, replay, self.device, cfg["ingest_chunk"])
         min_rows = max(int(cfg["min_replay_size"]), int(cfg["batch_size"]))
@@ -193,16 +203,27 @@ class Learner:
 
         while core.step < self.num_train_steps and not ctrl.stop:
             if len(replay) < min_rows or self._throttle():
-                if ingest.poll() == 0:
+                moved = ingest.poll()
+                if moved and dp is not None:
+                    dp.mark_inserted()
+                if moved == 0:
                     time.sleep(0.0005)
                 ctrl.heartbeat(0, int(time.time() * 1000))
                 continue
             if core.step % ingest_every == 0:
-                ingest.poll()
-            core.update_from_replay()
+                if ingest.poll() and dp is not None:
+                    dp.mark_inserted()
+            if dp is not None:
+                dp.update()
+            else:
+                core.update_from_replay()
             self._after_update(extra)
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
+        if dp is not None:
+            drift = dp.check_consistency()
+            if drift != 0.0:
+                raise RuntimeError(f"learner replicas diverged (checksum difference {drift})")
         if cfg.get("save_buffer_on_disk"):
             replay.dump(os.path.join(cfg["results_path"], "replay_buffer.pkl"))
         self._finish()

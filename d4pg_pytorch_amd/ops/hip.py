@@ -123,6 +123,26 @@ class SampleArgs(C.Structure):
                 ("total_steps", C.c_longlong)]
 
 
+class SampleRowsArgs(C.Structure):
+    _fields_ = [("rp", ReplayDesc), ("t", TreeDesc), ("st", vp), ("out", vp),
+                ("B", C.c_int), ("K", C.c_int), ("prioritized", C.c_int), ("pad_", C.c_int),
+                ("step", C.c_longlong),
+                ("per_b0", C.c_float), ("per_b1", C.c_float), ("total_steps", C.c_longlong)]
+
+
+class UnpackArgs(C.Structure):
+    _fields_ = [("in0", vp), ("in1", vp), ("st", vp), ("sa", vp), ("s_pi", vp), ("s2_a2", vp),
+                ("reward", vp), ("done", vp), ("gamma", vp), ("weights", vp), ("idx", vp),
+                ("B", C.c_int), ("Bl", C.c_int), ("K", C.c_int),
+                ("S", C.c_int), ("A", C.c_int), ("row_ld", C.c_int), ("ld_x", C.c_int),
+                ("do_tick", C.c_int), ("step0", C.c_longlong),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("per_b0", C.c_float), ("per_b1", C.c_float),
+                ("total_steps", C.c_longlong)]
+
+
+PACK_EXTRA = 4      # floats appended to a replay row in a packed batch (csrc/replay.hip)
+
+
 class ScatterBatchArgs(C.Structure):
     _fields_ = [("state", vp), ("action", vp), ("next_state", vp), ("sa", vp), ("s_pi", vp),
                 ("s2_a2", vp), ("B", C.c_int), ("S", C.c_int), ("A", C.c_int), ("ld_x", C.c_int)]
@@ -230,6 +250,8 @@ def lib() -> C.CDLL:
             ("d4pg_tree_update", [C.POINTER(TreeUpdateArgs), vp]),
             ("d4pg_replay_sample", [C.POINTER(SampleArgs), vp]),
             ("d4pg_scatter_batch", [C.POINTER(ScatterBatchArgs), vp]),
+            ("d4pg_replay_sample_rows", [C.POINTER(SampleRowsArgs), vp]),
+            ("d4pg_batch_unpack", [C.POINTER(UnpackArgs), vp]),
             ("d4pg_nstep", [C.POINTER(NstepArgs), vp]),
             ("d4pg_critic_phase", [C.POINTER(CriticPhaseArgs), C.c_int, vp]),
             ("d4pg_actor_phase", [C.POINTER(ActorPhaseArgs), C.c_int, vp]),
@@ -241,6 +263,9 @@ def lib() -> C.CDLL:
             fn.argtypes = argt
             fn.restype = C.c_int
         _lib.d4pg_devstate_size.restype = C.c_int
+        _lib.d4pg_pack_extra.restype = C.c_int
+        if _lib.d4pg_pack_extra() != PACK_EXTRA:
+            raise RuntimeError("packed-batch layout mismatch between csrc/replay.hip and ops/hip.py")
         if _lib.d4pg_devstate_size() != C.sizeof(DevStateMirror):
             raise RuntimeError("DevState layout mismatch between csrc/common.h and ops/hip.py")
     return _lib

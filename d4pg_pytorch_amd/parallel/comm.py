@@ -10,6 +10,9 @@ This framework scales the learner as one process per GPU; the ranks exchange
 
 all as single contiguous fp32 buffers (0.7-0.9 MB): on xGMI these messages are
 latency-bound, so one flat bucket per network is the right granularity.
+That is ``dp_mode: grad_allreduce`` (:func:`attach_data_parallel`).  The default
+``dp_mode: replicated`` (``replicated.py``) exchanges the sampled rows instead
+(one all-gather of ~20 KB per rank and update, overlapped with the update in flight).
 
 :class:`TorchDistComm` wraps ``torch.distributed`` (backend ``nccl`` == RCCL on
 ROCm, ``gloo`` on CPU).  :class:`LocalComm` is the world-size-1 no-op.
@@ -33,6 +36,10 @@ class Comm:
     def broadcast_(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:
         raise NotImplementedError
 
+    def all_gather_into_(self, out: torch.Tensor, inp: torch.Tensor) -> torch.Tensor:
+        """``out[rank * n:(rank + 1) * n] = inp`` of every rank (``n = inp.numel()``)."""
+        raise NotImplementedError
+
     def barrier(self) -> None:
         raise NotImplementedError
 
@@ -49,6 +56,11 @@ class LocalComm(Comm):
 
     def broadcast_(self, t, src=0):
         return t
+
+    def all_gather_into_(self, out, inp):
+        if out.data_ptr() != inp.data_ptr():
+            out.view(-1)[: inp.numel()].copy_(inp.reshape(-1))
+        return out
 
     def barrier(self):
         pass
@@ -94,6 +106,10 @@ class TorchDistComm(Comm):
     def broadcast_(self, t, src=0):
         self.dist.broadcast(t, src=src)
         return t
+
+    def all_gather_into_(self, out, inp):
+        self.dist.all_gather_into_tensor(out.view(-1), inp.reshape(-1))
+        return out
 
     def barrier(self):
         if self.backend == "nccl":

@@ -49,6 +49,21 @@ class ThreadComm(Comm):
         sh.barrier.wait()
         return t
 
+    def all_gather_into_(self, out: torch.Tensor, inp: torch.Tensor) -> torch.Tensor:
+        sh = self.shared
+        if inp.is_cuda:
+            torch.cuda.current_stream(inp.device).synchronize()     # stream-ordered producers of inp
+        sh.slots[self.rank] = inp.detach().reshape(-1).clone()
+        if inp.is_cuda:
+            torch.cuda.current_stream(inp.device).synchronize()
+        sh.barrier.wait()
+        with torch.no_grad():
+            out.view(-1).copy_(torch.cat([sh.slots[r] for r in range(self.world)]))
+        if out.is_cuda:
+            torch.cuda.current_stream(out.device).synchronize()
+        sh.barrier.wait()
+        return out
+
     def barrier(self) -> None:
         self.shared.barrier.wait()
 

@@ -162,12 +162,41 @@ class HbmReplay:
         a.total_steps = int(cfg["num_steps_train"])
         H.launch("d4pg_replay_sample", a, stream)
 
-    def enqueue_priority_update(self, idx: torch.Tensor, prio: torch.Tensor, n: int, stream=None) -> None:
+    def packed_width(self) -> int:
+        """Floats per row of a packed batch: the replay row, the importance weight and the slot."""
+        return self.row_ld + H.PACK_EXTRA
+
+    def sample_rows_args(self, out: torch.Tensor, n: int, chunk: int = 1) -> H.SampleRowsArgs:
+        """Launch descriptor of :meth:`enqueue_sample_rows` (reusable: set ``.step`` per call)."""
+        assert out.dtype == torch.float32 and out.is_contiguous()
+        assert out.numel() >= chunk * n * self.packed_width()
+        cfg = self.cfg
+        a = H.SampleRowsArgs()
+        a.rp, a.t, a.st = self._replay_desc(), self._tree_desc(), self.dev_state.data_ptr()
+        a.out, a.B, a.K, a.step = out.data_ptr(), int(n), int(chunk), 0
+        a.prioritized = 1 if self.prioritized else 0
+        a.per_b0, a.per_b1 = float(cfg["priority_beta_start"]), float(cfg["priority_beta_end"])
+        a.total_steps = int(cfg["num_steps_train"])
+        return a
+
+    def enqueue_sample_rows(self, out: torch.Tensor, n: int, step: int, chunk: int = 1, stream=None) -> None:
+        """Draw ``chunk`` batches of ``n`` rows into the packed buffer ``out[chunk, n, packed_width()]``
+        (enqueue only).  Batch ``j`` is the one update ``step + j`` consumes: ``step`` positions
+        the RNG stream and the importance-exponent schedule.  Unlike :meth:`enqueue_sample`
+        nothing is read from or written to the device step counter, so batches can be drawn ahead."""
+        a = self.sample_rows_args(out, n, chunk)
+        a.step = int(step)
+        H.launch("d4pg_replay_sample_rows", a, stream)
+
+    def priority_update_args(self, idx: torch.Tensor, prio: torch.Tensor, n: int) -> H.TreeUpdateArgs:
         a = H.TreeUpdateArgs()
         a.t = self._tree_desc()
         a.idx, a.prio, a.st = idx.data_ptr(), prio.data_ptr(), self.dev_state.data_ptr()
         a.n, a.alpha = int(n), self.alpha
-        H.launch("d4pg_tree_update", a, stream)
+        return a
+
+    def enqueue_priority_update(self, idx: torch.Tensor, prio: torch.Tensor, n: int, stream=None) -> None:
+        H.launch("d4pg_tree_update", self.priority_update_args(idx, prio, n), stream)
 
     def update_priorities(self, idx: torch.Tensor, prio: torch.Tensor) -> None:
         """``PrioritizedReplayBuffer.update_priorities`` (``replay_buffer.py:187-209``)."""

@@ -1,0 +1,140 @@
+"""Replicated data parallelism (parallel/replicated.py) on one GPU: world 1 against the plain
+replay path, two thread-ranks with an in-process all-gather against a single learner that is
+fed the same global batches, and a world-1 RCCL group for the collective wiring (GPU only)."""
+import os
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from d4pg_pytorch_amd.config import default_config
+
+pytestmark = pytest.mark.gpu
+
+GOLD = 0x9E3779B97F4A7C15
+
+
+def _cfg(B, per=0, dtype="bf16", graph=True, model="d4pg"):
+    return default_config(env="BipedalWalker-v2", model=model, batch_size=B, device="cuda", v_min=-10.0, v_max=10.0,
+                          replay_mem_size=40_000, replay_memory_prioritized=per, num_steps_train=1000,
+                          compute_dtype=dtype, use_hip_graph=graph, random_seed=7)
+
+
+def _rows(rp, n, seed):
+    g = torch.Generator().manual_seed(seed)
+    rows = torch.randn(n, rp.row_ld, generator=g)
+    S, A = rp.S, rp.A
+    rows[:, S + A + 1] = (torch.rand(n, generator=g) < 0.05).float()
+    rows[:, S + A + 2] = 0.95
+    return rows.cuda()
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_world_one_reproduces_the_plain_replay_path(dtype):
+    from d4pg_pytorch_amd.models.core import build_core
+    from d4pg_pytorch_amd.parallel.comm import LocalComm
+    from d4pg_pytorch_amd.parallel.replicated import attach_replicated
+    from d4pg_pytorch_amd.replay.hbm_replay import HbmReplay
+    cfg = _cfg(256, dtype=dtype)
+    outs = []
+    for mode in ("plain", "replicated"):
+        core = build_core(cfg, "cuda")
+        rp = HbmReplay(cfg, "cuda", core.dev_state)
+        rp.insert(_rows(rp, 20_000, 1))
+        if mode == "plain":
+            core.attach_replay(rp)
+            st = core.read_dev_state()
+            core._write_dev_state(step=0, seed=st.seed + GOLD, keep_replay=True)     # the stream rank 0 samples from
+            for _ in range(12):
+                core.update_from_replay()
+        else:
+            dp = attach_replicated(core, rp, LocalComm())
+            for _ in range(12):
+                dp.update()
+            assert dp.check_consistency() == 0.0
+        torch.cuda.synchronize()
+        m = core.read_metrics()
+        assert m["count"] == 12 and np.isfinite(m["value_loss"])
+        outs.append((core.online.flat.clone(), core.target.flat.clone(), core.idx.clone()))
+    assert torch.equal(outs[0][2], outs[1][2])            # same rows drawn
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("per", [0, 1])
+def test_two_thread_ranks_equal_one_learner_on_the_gathered_batches(per):
+    from d4pg_pytorch_amd.models.core import build_core
+    from d4pg_pytorch_amd.parallel.fake_comm import ThreadComm
+    from d4pg_pytorch_amd.parallel.replicated import attach_replicated
+    from d4pg_pytorch_amd.replay.hbm_replay import HbmReplay
+    world, Bl, steps = 2, 128, 11                # chunks of 4 batches: crosses two chunk boundaries
+    cfg_g = _cfg(Bl * world, per=per, graph=False)          # graph capture is process-global: threads run eagerly
+    comms = ThreadComm.group(world)
+    cores, dps, seen, errs = [None] * world, [None] * world, [], []
+
+    def run(r):
+        try:
+            torch.cuda.set_device(0)
+            core = build_core(cfg_g, "cuda", seed=100 + r)            # different inits: rank 0 is broadcast
+            rp = HbmReplay(cfg_g, "cuda", core.dev_state)
+            rp.insert(_rows(rp, 10_000, 10 + r))                      # different shards
+            dp = attach_replicated(core, rp, comms[r], Bl, chunk=4)
+            cores[r], dps[r] = core, dp
+            for _ in range(steps):
+                batch = dp.current_batch()            # (a collective on the first call: every rank makes it)
+                if r == 0:
+                    seen.append(batch)
+                dp.update()
+            assert dp.check_consistency() == 0.0
+        except Exception as e:    # pragma: no cover
+            errs.append(e)
+            comms[r].shared.barrier.abort()
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join(180) for t in ts]
+    assert not errs, errs
+    assert torch.equal(cores[0].online.flat, cores[1].online.flat)
+    assert torch.equal(cores[0].target.flat, cores[1].target.flat)
+    # the two halves of a gathered batch come from the two shards
+    S, A = cores[0].S, cores[0].A
+    assert not torch.equal(seen[0][:Bl, :S], seen[0][Bl:, :S])
+    # a single learner fed the same global batches makes the same updates
+    single = build_core(cfg_g, "cuda", seed=100)
+    row_ld = dps[0].replay.row_ld
+    for b in seen:
+        single.update_from_packed(b, row_ld)
+    torch.cuda.synchronize()
+    assert torch.equal(single.online.flat, cores[0].online.flat)
+    assert torch.equal(single.target.flat, cores[1].target.flat)
+    if per:
+        # each rank wrote back only its own half: priorities of sampled rows moved off the initial value
+        for r in range(world):
+            leaf = dps[r].replay.leaf[:10_000]
+            assert (leaf != leaf.max()).sum().item() >= Bl // 2
+
+
+def test_rccl_world_one_all_gather_wiring():
+    from d4pg_pytorch_amd.models.core import build_core
+    from d4pg_pytorch_amd.parallel.comm import TorchDistComm
+    from d4pg_pytorch_amd.parallel.replicated import attach_replicated
+    from d4pg_pytorch_amd.replay.hbm_replay import HbmReplay
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(30100 + os.getpid() % 100), RANK="0", WORLD_SIZE="1")
+    comm = TorchDistComm(device=torch.device("cuda", 0), rank=0, world=1)
+    try:
+        cfg = _cfg(256, per=1)
+        core = build_core(cfg, "cuda")
+        rp = HbmReplay(cfg, "cuda", core.dev_state)
+        rp.insert(_rows(rp, 20_000, 3))
+        dp = attach_replicated(core, rp, comm)
+        out = torch.zeros(8, device="cuda")
+        comm.all_gather_into_(out, torch.arange(8.0, device="cuda"))
+        assert torch.equal(out, torch.arange(8.0, device="cuda"))
+        for _ in range(20):
+            dp.update()
+        torch.cuda.synchronize()
+        m = core.read_metrics()
+        assert m["count"] == 20 and np.isfinite(m["value_loss"]) and np.isfinite(m["policy_loss"])
+        assert dp.check_consistency() == 0.0
+    finally:
+        comm.close()
