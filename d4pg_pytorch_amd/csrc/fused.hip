@@ -1016,19 +1016,23 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGroup g) {
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     float asum = 0.f;
     const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 4
+    // the bias gradient (row sums of dY) is only needed from the first tile column
+    const bool want_rowsum = d.rowsum != nullptr && tn == 0;
+#pragma unroll 8
     for (int ks = k0; ks < k1; ++ks) {
         bf16x8 av = *reinterpret_cast<const bf16x8*>(arow + ks * 16);
         bf16x8 bv = *reinterpret_cast<const bf16x8*>(brow + ks * 16);
         av = m_ok ? av : zero;
         bv = n_ok ? bv : zero;
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
+        if (want_rowsum) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) asum += (float)av[j];
+            for (int j = 0; j < 8; ++j) asum += (float)av[j];
+        }
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) red[(wave * 16 + i) * 64 + lane] = acc[i];
-    if (d.rowsum != nullptr) {
+    if (want_rowsum) {
         asum += __shfl_xor(asum, 32, 64);
         if (lane < 32) cs[wave * 32 + lane] = asum;
     }

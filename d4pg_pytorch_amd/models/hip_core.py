@@ -28,6 +28,7 @@ flat gradient range runs between them.
 from __future__ import annotations
 
 import ctypes as C
+import gc
 from typing import Callable, Dict, List, Optional
 
 import torch
@@ -332,12 +333,22 @@ class HipCore(CoreBase):
         self._restore(snap)
         groups = [segs] if fused else [[f] for f in segs]
         graphs = []
-        for grp in groups:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                for f in grp:
-                    f()
-            graphs.append(g)
+        # No garbage collection while a stream is capturing: a collected tensor or event is
+        # released through hipFree / hipEventDestroy, which is illegal during capture and
+        # aborts the process.
+        gc.collect()
+        gc_was_enabled = gc.isenabled()
+        gc.disable()
+        try:
+            for grp in groups:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    for f in grp:
+                        f()
+                graphs.append(g)
+        finally:
+            if gc_was_enabled:
+                gc.enable()
         # capture does not execute; nothing to restore
         return graphs
 

@@ -55,9 +55,11 @@ class HipCoreBf16(HipCore):
         self.sT, self.a_h1T, self.a_h2T = stash(S), stash(Hd), stash(Hd)
         self.a_daT, self.a_dh2T, self.a_dh1T = stash(A), stash(Hd), stash(Hd)
         self.dims = self._phase_dims()
-        # rows per workgroup: 32 when it fits LDS and leaves enough workgroups, else 16
+        # rows per workgroup: a phase is a latency-bound chain whose length does not depend on the
+        # number of workgroups until they outnumber the 256 CUs, so 16-row tiles (more, smaller
+        # workgroups) win up to B = 4096; beyond that 32-row tiles halve the weight traffic
         self.mt = 1
-        if B % 32 == 0 and B // 32 >= 64:
+        if B % 32 == 0 and B // 16 > 256:
             need = max(H.lib().d4pg_phase_lds_bytes(self.dims, 2, 0), H.lib().d4pg_phase_lds_bytes(self.dims, 2, 1))
             if need <= LDS_LIMIT:
                 self.mt = 2
