@@ -53,7 +53,7 @@ def torch_lib_dir() -> str:
 
 def build_hip(force: bool = False, verbose: bool = False) -> str:
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "loss_dev.h")]
+    headers = [os.path.join(CSRC, h) for h in ("common.h", "loss_dev.h", "replay_dev.h")]
     deps = srcs + headers
     if not force and not _stale(HIP_LIB, deps):
         return HIP_LIB

@@ -101,6 +101,7 @@ EXTENSION_DEFAULTS: Dict[str, Any] = {
     "metrics_interval": 100,         # device-side metric accumulator is read back every N updates
     "ring_capacity": 4096,           # rows per explorer->replay shared-memory ring
     "ingest_chunk": 1024,            # rows per pinned H2D staging chunk
+    "ingest_interval": 32,           # learner updates between two drains of the explorer rings
     # --- lifecycle ---
     "resume": None,                  # path to a learner checkpoint bundle to resume from
     "learner_checkpoint_interval": 0,  # 0 = only at the end
@@ -136,7 +137,7 @@ _INT_KEYS = {
     "max_ep_length", "replay_mem_size", "n_step_returns", "update_agent_ep", "replay_queue_size",
     "batch_queue_size", "replay_memory_prioritized", "num_episode_save", "save_buffer_on_disk",
     "dense_size", "num_atoms", "num_learners", "envs_per_agent", "weight_publish_interval",
-    "max_env_steps_per_agent", "metrics_interval", "ring_capacity", "ingest_chunk",
+    "max_env_steps_per_agent", "metrics_interval", "ring_capacity", "ingest_chunk", "ingest_interval",
     "ou_decay_period", "learner_checkpoint_interval",
 }
 _FLOAT_KEYS = {

@@ -68,10 +68,25 @@ __device__ __forceinline__ float wave_sum(float v) {
     v += dpp_mov<0x128>(v);   // row_ror 8
     return (row_lane(v, 0) + row_lane(v, 16)) + (row_lane(v, 32) + row_lane(v, 48));
 }
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_d(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xFFFFFFFFll), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double row_lane_d(double v, int l) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFll), l);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
 __device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_mov_d<0xb1>(v);
+    v += dpp_mov_d<0x4e>(v);
+    v += dpp_mov_d<0x124>(v);
+    v += dpp_mov_d<0x128>(v);
+    return (row_lane_d(v, 0) + row_lane_d(v, 16)) + (row_lane_d(v, 32) + row_lane_d(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
     v = fmaxf(v, dpp_mov<0xb1>(v));

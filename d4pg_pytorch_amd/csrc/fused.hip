@@ -24,6 +24,7 @@
 // B / (16*MT) exceeds the 256 CUs.
 #include "common.h"
 #include "loss_dev.h"
+#include "replay_dev.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -613,6 +614,11 @@ struct ActorPhaseArgs {
     __bf16* dh2T;
     __bf16* dh1T;
     float* q_val;          // [B]
+    // Priority write-back of the prioritised replay, run by ONE extra workgroup of this launch
+    // (block B / M) while the others do the actor phase: it only needs the priorities the
+    // critic phase wrote, and must be finished before the next update samples.  Forking it
+    // onto a second stream inside the graph instead costs ~10 us per cross-queue dependency.
+    TreeUpdateArgs tree;   // tree.n == 0: none
 };
 
 template <int SL, int M>
@@ -650,6 +656,10 @@ __global__ __launch_bounds__(64 * NW) void actor_phase_kernel(const ActorPhaseAr
     const int row0 = blockIdx.x * M;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (row0 >= d.B) {         // the extra workgroup
+        tree_update_body<NW>(a.tree);
+        return;
+    }
     STAMP(1, 31);
     Chain<MT, KSH, KSN> ch;
     ch.prefetch_n(a.af[0]);
@@ -842,7 +852,7 @@ static int launch_phase(K kernel, const Args& a, int grid, int lds, hipStream_t 
     int rc = check_dims(d, M);                                                              \
     if (rc) return rc;                                                                      \
     const int lds = LDSFN(d, M);                                                            \
-    const int grid = d.B / M;                                                               \
+    const int grid = d.B / M + extra_blocks;                                                \
     const int ksh = (d.ldh - LDS_PAD) / 32;                                                 \
     if (mt == 1) {                                                                          \
         if (ksn <= 2) DISPATCH_KSH(KERNEL, 1, 2);                                           \
@@ -861,6 +871,7 @@ D4PG_API int d4pg_critic_phase(const CriticPhaseArgs* a, int mt, hipStream_t str
         if (check_hidden(a->ta[i], ksh_) || check_hidden(a->tc[i], ksh_) || check_hidden(a->cf[i], ksh_)) return -10;
     if (check_hidden(a->cb2, ksh_)) return -10;
     const int ksn = max3i(a->cb3.ks, a->ta[0].ks, max3i(a->tc[0].ks, a->cf[0].ks, 0));
+    const int extra_blocks = 0;
     DISPATCH_PHASE(critic_phase_kernel, phase_lds_bytes_critic)
 }
 
@@ -876,6 +887,10 @@ D4PG_API int d4pg_actor_phase(const ActorPhaseArgs* a, int mt, hipStream_t strea
         if (check_hidden(a->af[i], ksh_) || check_hidden(a->cf[i], ksh_)) return -10;
     if (check_hidden(a->cb2, ksh_) || check_hidden(a->cb1, ksh_) || check_hidden(a->ab2, ksh_)) return -10;
     const int ksn = max3i(a->af[0].ks, a->cf[0].ks, max3i(a->cb3.ks, a->ab3.ks, 0));
+    if (a->tree.n < 0 || (a->tree.n > 0 && (a->tree.idx == nullptr || a->tree.prio == nullptr ||
+                                            a->tree.t.L < 0 || a->tree.t.L > MAXL)))
+        return -11;
+    const int extra_blocks = a->tree.n > 0 ? 1 : 0;
     DISPATCH_PHASE(actor_phase_kernel, phase_lds_bytes_actor)
 }
 

@@ -18,45 +18,7 @@
 // the weight reduces to w_i = (p_min / p_i)^beta.
 #include "common.h"
 
-constexpr int MAXL = 6;
-
-struct TreeDesc {
-    float* leaf;            // [n[0]] priority^alpha, 0 for empty slots
-    double* sum[MAXL + 1];  // sum[l], l = 1..L : [n[l]] fp64 sums of 64 children
-    float* mn[MAXL + 1];    // mn[l],  l = 1..L : [n[l]] min over non-empty leaves below (+inf if none)
-    long long n[MAXL + 1];  // entries per level, each padded to a multiple of 64; n[L] <= 64
-    int L;                  // top level index (0: the leaves themselves fit one node)
-    int pad_;
-};
-
-struct ReplayDesc {
-    float* rows;            // [capacity, row_ld]
-    long long capacity;
-    int S, A, row_ld;
-    int pad_;
-};
-
-__device__ __forceinline__ double tree_load_sum(const TreeDesc& t, int level, long long idx) {
-    if (idx >= t.n[level]) return 0.0;
-    return level == 0 ? (double)t.leaf[idx] : t.sum[level][idx];
-}
-__device__ __forceinline__ float tree_load_min(const TreeDesc& t, int level, long long idx) {
-    if (idx >= t.n[level]) return INFINITY;
-    if (level == 0) {
-        const float v = t.leaf[idx];
-        return v > 0.f ? v : INFINITY;
-    }
-    return t.mn[level][idx];
-}
-
-__device__ __forceinline__ double wave_scan_incl_d(double v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const double u = __shfl_up(v, o, 64);
-        if (lane >= o) v += u;
-    }
-    return v;
-}
+#include "replay_dev.h"
 
 // ---------------------------------------------------------------------------
 // Insert a staged chunk of rows at the ring cursor.
@@ -107,47 +69,10 @@ D4PG_API int d4pg_replay_insert(const InsertArgs* a, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------
-// Tree update: leaf[idx[i]] = priority[i]^alpha, then recompute every touched
-// ancestor level by level.  One workgroup (16 waves); __syncthreads() between
-// levels orders the global writes of one level before the reads of the next.
-struct TreeUpdateArgs {
-    TreeDesc t;
-    const long long* idx;   // [n]
-    const float* prio;      // [n] raw priorities
-    DevState* st;
-    int n;
-    float alpha;
-};
-
-__global__ __launch_bounds__(1024) void tree_update_kernel(const TreeUpdateArgs a) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float local_max = 0.f;
-    for (int i = tid; i < a.n; i += 1024) {
-        float p = a.prio[i];
-        if (!(p > 0.f) || p > 3.0e38f) p = 1e-4f;   // NaN / inf / non-positive never enter the tree
-        a.t.leaf[a.idx[i]] = powf(p, a.alpha);
-        local_max = fmaxf(local_max, p);
-    }
-    local_max = wave_max(local_max);
-    // positive floats order like their bit patterns
-    if (lane == 0 && local_max > 0.f)
-        atomicMax(reinterpret_cast<unsigned int*>(&a.st->max_priority), __float_as_uint(local_max));
-    __syncthreads();
-    for (int l = 1; l <= a.t.L; ++l) {
-        for (int i = wave; i < a.n; i += 16) {
-            const long long g = a.idx[i] >> (6 * l);
-            if (i > 0 && (a.idx[i - 1] >> (6 * l)) == g) continue;   // adjacent duplicate parent
-            const long long c = g * 64 + lane;
-            const double s = wave_sum_d(tree_load_sum(a.t, l - 1, c));
-            const float m = wave_min(tree_load_min(a.t, l - 1, c));
-            if (lane == 0) {
-                a.t.sum[l][g] = s;
-                a.t.mn[l][g] = m;
-            }
-        }
-        __syncthreads();
-    }
-}
+// Tree update as a stand-alone launch (one workgroup of 16 waves); the body lives in
+// replay_dev.h because the fused bf16 pipeline runs it as an extra workgroup of its actor
+// phase kernel.
+__global__ __launch_bounds__(1024) void tree_update_kernel(const TreeUpdateArgs a) { tree_update_body<16>(a); }
 
 D4PG_API int d4pg_tree_update(const TreeUpdateArgs* a, hipStream_t stream) {
     if (a->n < 1 || a->t.L < 0 || a->t.L > MAXL) return -1;

@@ -84,6 +84,7 @@ class HipCore(CoreBase):
         self._side = torch.cuda.Stream(device=dev)
         self.packed_unpack: Dict[str, H.UnpackArgs] = {}     # batch sources registered by register_packed()
         self.packed_prio = None
+        self._fork_join = None       # event of a forked priority write-back still to be joined
 
     # ------------------------------------------------------------------ state
     def _write_dev_state(self, step: int, seed: Optional[int] = None, keep_replay: bool = False) -> None:
@@ -246,7 +247,13 @@ class HipCore(CoreBase):
                                    H.EPI_MUL_RELU_MASK, self.h1_c, ldh)])
             H.gemm_group([self._dw(self.dh1, ldh, self.sa, ldx, c_on[0])])
             if forked is not None:
-                torch.cuda.current_stream().wait_event(forked)
+                if self.grad_sync is None:
+                    # one graph holds the whole update: the priority write-back only has to be
+                    # finished before the NEXT update samples, so it joins at the very end and
+                    # overlaps the actor phase
+                    self._fork_join = forked
+                else:
+                    torch.cuda.current_stream().wait_event(forked)
 
         def seg_actor() -> None:
             H.launch("d4pg_adam_polyak", adam_args(lay.critic, self.lr_critic, 0))
@@ -284,8 +291,14 @@ class HipCore(CoreBase):
 
         def seg_finish() -> None:
             H.launch("d4pg_adam_polyak", adam_args(lay.actor, self.lr_actor, 1))
+            self._join_fork()
 
         return [seg_critic, seg_actor, seg_finish]
+
+    def _join_fork(self) -> None:
+        if self._fork_join is not None:
+            torch.cuda.current_stream().wait_event(self._fork_join)
+            self._fork_join = None
 
     # ------------------------------------------------------------------- run
     def _segments(self, source: str) -> List[Callable[[], None]]:

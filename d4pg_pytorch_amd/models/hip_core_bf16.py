@@ -216,25 +216,10 @@ class HipCoreBf16(HipCore):
             a.dlT, a.dh2T, a.dh1T = self.c_dlT.data_ptr(), self.c_dh2T.data_ptr(), self.c_dh1T.data_ptr()
             a.per_loss, a.priority = self.per_loss.data_ptr(), self.prio.data_ptr()
             H._check(H.lib().d4pg_critic_phase(a, self.mt, H.stream_ptr()), "d4pg_critic_phase")
-            forked = None
-            packed_prio = self.packed_prio if source in self.packed_unpack else None
-            if (source == "replay" and self.replay.prioritized) or packed_prio is not None:
-                main = torch.cuda.current_stream()
-                ev = torch.cuda.Event()
-                ev.record(main)
-                self._side.wait_event(ev)
-                with torch.cuda.stream(self._side):
-                    if packed_prio is not None:
-                        H.launch("d4pg_tree_update", packed_prio)      # this rank's rows of the global batch
-                    else:
-                        self.replay.enqueue_priority_update(self.idx, self.prio, self.B)
-                    forked = torch.cuda.Event()
-                    forked.record(self._side)
+            # the priority write-back rides along with the actor phase (seg_actor)
             self._wgrad([(self.c_dlT, self.c_h2T, cl[2], sl.critic[2]), (self.c_dh2T, self.c_h1T, cl[1], sl.critic[1]),
                          (self.c_dh1T, self.saT, cl[0], sl.critic[0])],
                         opt=(self.lr_critic, False) if fuse_opt else None)
-            if forked is not None:
-                torch.cuda.current_stream().wait_event(forked)
 
         def seg_actor() -> None:
             if not fuse_opt:
@@ -253,6 +238,10 @@ class HipCoreBf16(HipCore):
             a.sT, a.h1T, a.h2T = self.sT.data_ptr(), self.a_h1T.data_ptr(), self.a_h2T.data_ptr()
             a.daT, a.dh2T, a.dh1T = self.a_daT.data_ptr(), self.a_dh2T.data_ptr(), self.a_dh1T.data_ptr()
             a.q_val = self.q_val.data_ptr()
+            if source == "replay" and self.replay.prioritized:
+                a.tree = self.replay.priority_update_args(self.idx, self.prio, self.B)
+            elif source in self.packed_unpack and self.packed_prio is not None:
+                a.tree = self.packed_prio      # this rank's rows of the global batch
             H._check(H.lib().d4pg_actor_phase(a, self.mt, H.stream_ptr()), "d4pg_actor_phase")
             self._wgrad([(self.a_daT, self.a_h2T, al[2], sl.actor[2]), (self.a_dh2T, self.a_h1T, al[1], sl.actor[1]),
                          (self.a_dh1T, self.sT, al[0], sl.actor[0])],
@@ -261,5 +250,6 @@ class HipCoreBf16(HipCore):
         def seg_finish() -> None:
             if not fuse_opt:
                 H.launch("d4pg_adam_polyak", adam_args(lay.actor, sl.actor, self.lr_actor, 1))
+            self._join_fork()
 
         return [seg_critic, seg_actor, seg_finish]

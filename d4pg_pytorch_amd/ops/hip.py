@@ -176,7 +176,8 @@ class CriticPhaseArgs(C.Structure):
 class ActorPhaseArgs(C.Structure):
     _fields_ = [("d", PhaseDims), ("s", vp), ("af", LayerW * 3), ("cf", LayerW * 3),
                 ("cb3", LayerW), ("cb2", LayerW), ("cb1", LayerW), ("ab3", LayerW), ("ab2", LayerW),
-                ("sT", vp), ("h1T", vp), ("h2T", vp), ("daT", vp), ("dh2T", vp), ("dh1T", vp), ("q_val", vp)]
+                ("sT", vp), ("h1T", vp), ("h2T", vp), ("daT", vp), ("dh2T", vp), ("dh1T", vp), ("q_val", vp),
+                ("tree", TreeUpdateArgs)]
 
 
 class WgradDesc(C.Structure):
