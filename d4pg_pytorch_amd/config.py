@@ -102,6 +102,7 @@ EXTENSION_DEFAULTS: Dict[str, Any] = {
     "ring_capacity": 4096,           # rows per explorer->replay shared-memory ring
     "ingest_chunk": 1024,            # rows per pinned H2D staging chunk
     "ingest_interval": 32,           # learner updates between two drains of the explorer rings
+    "sample_ahead": 8,               # uniform replay, bf16 pipeline: batches drawn per sampling launch (1: every update)
     # --- lifecycle ---
     "resume": None,                  # path to a learner checkpoint bundle to resume from
     "learner_checkpoint_interval": 0,  # 0 = only at the end
@@ -137,7 +138,7 @@ _INT_KEYS = {
     "max_ep_length", "replay_mem_size", "n_step_returns", "update_agent_ep", "replay_queue_size",
     "batch_queue_size", "replay_memory_prioritized", "num_episode_save", "save_buffer_on_disk",
     "dense_size", "num_atoms", "num_learners", "envs_per_agent", "weight_publish_interval",
-    "max_env_steps_per_agent", "metrics_interval", "ring_capacity", "ingest_chunk", "ingest_interval",
+    "max_env_steps_per_agent", "metrics_interval", "ring_capacity", "ingest_chunk", "ingest_interval", "sample_ahead",
     "ou_decay_period", "learner_checkpoint_interval",
 }
 _FLOAT_KEYS = {

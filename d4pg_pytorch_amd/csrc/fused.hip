@@ -334,6 +334,44 @@ __device__ __forceinline__ void put_stash4(__bf16* XT, int ldt, int col, int b0,
     *reinterpret_cast<bf16x4*>(XT + (size_t)col * ldt + b0) = o;
 }
 
+// Batch rows read straight out of the gathered chunk buffers of csrc/replay.hip (packed rows
+// [s | a | r | done | gamma^k | s' | weight | slot]), so that no per-update kernel has to
+// copy them into separate input matrices.  Which chunk buffer and which batch of the chunk
+// follow from the device step counter, exactly as in batch_unpack_kernel.
+struct PackedIn {
+    const float* in0;        // gathered chunk, even chunks  [world][K][Bl][row_ld + 4]
+    const float* in1;        // gathered chunk, odd chunks
+    DevState* st;
+    long long step0;         // device step counter at the first batch of chunk 0
+    int K, Bl, row_ld;
+    int enabled;             // 0: the plain input arrays of the phase arguments are used
+    int do_tick;             // the critic phase performs the per-update tick (block 0, thread 0)
+    float beta1, beta2, per_b0, per_b1;
+    int pad_;
+    long long total_steps;
+};
+
+// Where batch row b of some input lives:  base + (b / Bl) * rank_stride + (b % Bl) * stride.
+struct RowSrc {
+    const float* base;
+    long long stride, rank_stride;
+    int Bl;
+};
+__device__ __forceinline__ RowSrc plain_src(const float* base, long long stride, int B) {
+    return RowSrc{base, stride, 0, B > 0 ? B : 1};
+}
+__device__ __forceinline__ RowSrc packed_src(const PackedIn& p, int col0) {
+    const long long s = p.st->step_done - p.step0;
+    const int j = (int)(s % p.K);
+    const float* chunk = ((s / p.K) & 1) ? p.in1 : p.in0;
+    const long long ldp = p.row_ld + 4;
+    return RowSrc{chunk + (long long)j * p.Bl * ldp + col0, ldp, (long long)p.K * p.Bl * ldp, p.Bl};
+}
+__device__ __forceinline__ const float* row_of(const RowSrc& r, int b) {
+    const int q = b / r.Bl;
+    return r.base + q * r.rank_stride + (b - q * r.Bl) * r.stride;
+}
+
 struct PhaseDims {
     int B;            // batch rows (multiple of 16*MT)
     int Bp;           // leading dimension of the transposed stashes (multiple of 32, >= B)
@@ -360,6 +398,7 @@ struct CriticPhaseArgs {
     const float* done;
     const float* gamma;
     const float* weights;  // may be null
+    PackedIn pk;           // pk.enabled: rows come from the packed chunk buffers instead of the six arrays above
     LayerW ta[3];          // target actor, forward
     LayerW tc[3];          // target critic, forward
     LayerW cf[3];          // online critic, forward
@@ -391,16 +430,16 @@ __device__ __forceinline__ void zero_tail(__bf16* buf, int ld, int M, int c0) {
     }
 }
 
-// Load `ncols` fp32 columns of M rows into a bf16 LDS tile whose remaining columns (up to
+// Load `ncols` fp32 columns of M batch rows into a bf16 LDS tile whose remaining columns (up to
 // ld_dst) are written as zeros, so the tile needs no separate clearing pass; optionally
 // also into a transposed global stash.
-__device__ __forceinline__ void load_input(const float* __restrict__ src, int ld_src, int row0, int M, int ncols,
-                                           __bf16* dst, int ld_dst, __bf16* stashT, int ldt) {
+__device__ __forceinline__ void load_input(const RowSrc& src, int row0, int M, int ncols, __bf16* dst, int ld_dst,
+                                           __bf16* stashT, int ldt) {
     for (int i = threadIdx.x; i < M * ld_dst; i += blockDim.x) {
         const int r = i / ld_dst, c = i - r * ld_dst;
         float v = 0.f;
         if (c < ncols) {
-            v = src[(size_t)(row0 + r) * ld_src + c];
+            v = row_of(src, row0 + r)[c];
             if (stashT != nullptr) stashT[(size_t)c * ldt + row0 + r] = (__bf16)v;
         }
         dst[r * ld_dst + c] = (__bf16)v;
@@ -486,14 +525,29 @@ __global__ __launch_bounds__(64 * NW) void critic_phase_kernel(const CriticPhase
     float* sb = (float*)carve(NW * 256 * 4);
     float* rs = (float*)carve(4 * M * 4);           // reward | 1 - done | gamma | weight / B
     // per-row scalars of the loss: fetched now (registers), parked in LDS behind the inputs
+    const int SA = d.S + d.A;
+    const RowSrc src_sa = a.pk.enabled ? packed_src(a.pk, 0) : plain_src(a.sa, d.ldx_in, d.B);
+    const RowSrc src_s2 = a.pk.enabled ? packed_src(a.pk, SA + 3) : plain_src(a.s2, d.ldx_in, d.B);
     float rs_r = 0.f, rs_nd = 0.f, rs_g = 0.f, rs_w = 0.f;
     if (threadIdx.x < M) {
         const int b = row0 + threadIdx.x;
-        rs_r = a.reward[b];
-        rs_nd = 1.f - a.done[b];
-        rs_g = d.fixed_gamma >= 0.f ? d.fixed_gamma : a.gamma[b];
-        rs_w = (a.weights ? a.weights[b] : 1.f) * d.inv_B;
+        if (a.pk.enabled) {
+            const float* row = row_of(src_sa, b);
+            rs_r = row[SA];
+            rs_nd = 1.f - row[SA + 1];
+            rs_g = d.fixed_gamma >= 0.f ? d.fixed_gamma : row[SA + 2];
+            rs_w = row[a.pk.row_ld] * d.inv_B;
+        } else {
+            rs_r = a.reward[b];
+            rs_nd = 1.f - a.done[b];
+            rs_g = d.fixed_gamma >= 0.f ? d.fixed_gamma : a.gamma[b];
+            rs_w = (a.weights ? a.weights[b] : 1.f) * d.inv_B;
+        }
     }
+    // the per-update tick reads step_done (like packed_src above) and writes step_cur / bc1 / bc2 /
+    // per_beta, which nothing in this kernel reads
+    if (a.pk.enabled && a.pk.do_tick && blockIdx.x == 0 && threadIdx.x == 0)
+        devstate_tick(a.pk.st, a.pk.beta1, a.pk.beta2, a.pk.per_b0, a.pk.per_b1, a.pk.total_steps);
     // K-padding columns are never written by an epilogue: clear them once (the matching
     // weight columns are zero, but LDS garbage could be NaN)
     zero_block(dlg, M * d.ldd * 2);
@@ -502,8 +556,8 @@ __global__ __launch_bounds__(64 * NW) void critic_phase_kernel(const CriticPhase
     zero_tail(bufC, d.ldh, M, d.H);
     zero_tail(bufD, d.ldh, M, d.H);
     STAMP(0, 0);
-    load_input(a.sa, d.ldx_in, row0, M, d.S + d.A, xin, d.ldx, a.saT, d.Bp);
-    load_input(a.s2, d.ldx_in, row0, M, d.S, xin2, d.ldx, nullptr, 0);
+    load_input(src_sa, row0, M, SA, xin, d.ldx, a.saT, d.Bp);
+    load_input(src_s2, row0, M, d.S, xin2, d.ldx, nullptr, 0);
     if (threadIdx.x < M) {
         rs[threadIdx.x] = rs_r;
         rs[M + threadIdx.x] = rs_nd;
@@ -603,6 +657,7 @@ __global__ __launch_bounds__(64 * NW) void critic_phase_kernel(const CriticPhase
 struct ActorPhaseArgs {
     PhaseDims d;
     const float* s;        // [B, ldx_in] state (action columns ignored)
+    PackedIn pk;           // pk.enabled: states come from the packed chunk buffers instead
     LayerW af[3];          // online actor, forward
     LayerW cf[3];          // online critic (already updated), forward
     LayerW cb3, cb2, cb1;  // critic backward: layers 3, 2 and the action columns of layer 1
@@ -681,7 +736,8 @@ __global__ __launch_bounds__(64 * NW) void actor_phase_kernel(const ActorPhaseAr
     zero_tail(bufC, d.ldh, M, d.H);
     zero_tail(bufD, d.ldh, M, d.H);
     STAMP(1, 0);
-    load_input(a.s, d.ldx_in, row0, M, d.S, xin, d.ldx, a.sT, d.Bp);
+    load_input(a.pk.enabled ? packed_src(a.pk, 0) : plain_src(a.s, d.ldx_in, d.B), row0, M, d.S, xin, d.ldx, a.sT,
+               d.Bp);
     __syncthreads();
     STAMP(1, 1);
     // ---- actor forward ----
@@ -821,6 +877,12 @@ static int check_layer(const LayerW& L, int k32_max) {
     if (((uintptr_t)L.W) & 15) return -7;
     return 0;
 }
+static int check_packed(const PackedIn& p, const PhaseDims& d) {
+    if (!p.enabled) return 0;
+    if (p.in0 == nullptr || p.in1 == nullptr || p.st == nullptr) return -12;
+    if (p.K < 1 || p.Bl < 1 || d.B % p.Bl || p.row_ld < 2 * d.S + d.A + 3) return -13;
+    return 0;
+}
 static int max3i(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
 // hidden-K layers run the compile-time path: their K-steps must be the kernel's
 static int check_hidden(const LayerW& L, int ksh) { return L.ks == ksh ? 0 : -10; }
@@ -872,6 +934,7 @@ D4PG_API int d4pg_critic_phase(const CriticPhaseArgs* a, int mt, hipStream_t str
     if (check_hidden(a->cb2, ksh_)) return -10;
     const int ksn = max3i(a->cb3.ks, a->ta[0].ks, max3i(a->tc[0].ks, a->cf[0].ks, 0));
     const int extra_blocks = 0;
+    if (int prc = check_packed(a->pk, a->d)) return prc;
     DISPATCH_PHASE(critic_phase_kernel, phase_lds_bytes_critic)
 }
 
@@ -891,6 +954,7 @@ D4PG_API int d4pg_actor_phase(const ActorPhaseArgs* a, int mt, hipStream_t strea
                                             a->tree.t.L < 0 || a->tree.t.L > MAXL)))
         return -11;
     const int extra_blocks = a->tree.n > 0 ? 1 : 0;
+    if (int prc = check_packed(a->pk, a->d)) return prc;
     DISPATCH_PHASE(actor_phase_kernel, phase_lds_bytes_actor)
 }
 

@@ -83,6 +83,7 @@ class HipCore(CoreBase):
         self._segments_cache: Dict[str, List[Callable[[], None]]] = {}
         self._side = torch.cuda.Stream(device=dev)
         self.packed_unpack: Dict[str, H.UnpackArgs] = {}     # batch sources registered by register_packed()
+        self.packed_direct: Dict[str, H.PackedIn] = {}       # sources the kernels read in place (bf16 pipeline)
         self.packed_prio = None
         self._fork_join = None       # event of a forked priority write-back still to be joined
 
@@ -451,6 +452,8 @@ class HipCore(CoreBase):
         self.packed_prio = prio_args
         self._graphs = {k: v for k, v in self._graphs.items() if not k.startswith(name)}
         self._segments_cache = {k: v for k, v in self._segments_cache.items() if not k.startswith(name)}
+
+    supports_direct_input = False     # the fused bf16 pipeline reads packed chunk rows in place
 
     def update_from_source(self, name: str) -> torch.Tensor:
         """One update on the registered packed batch source ``name``; returns the priorities."""

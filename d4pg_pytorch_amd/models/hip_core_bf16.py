@@ -70,6 +70,46 @@ class HipCoreBf16(HipCore):
                              f"use compute_dtype: fp32")
         self.refresh_shadows()
 
+    supports_direct_input = True
+
+    def register_direct(self, name: str, chunk0: torch.Tensor, chunk1: torch.Tensor, row_ld: int,
+                        local_batch: int, chunk: int = 1) -> None:
+        """Like :meth:`register_packed`, but the phase kernels read the rows of the batch in flight
+        straight out of the gathered chunk buffers (no unpack kernel, no copy into the input
+        matrices; the critic phase performs the tick).  Slots are not extracted, so this is for
+        uniform replay; prioritised replay goes through :meth:`register_packed`."""
+        u = self.unpack_args(chunk0, chunk1, row_ld, local_batch, chunk)      # validates the buffers
+        pk = H.PackedIn()
+        pk.in0, pk.in1, pk.st, pk.step0 = u.in0, u.in1, u.st, u.step0
+        pk.K, pk.Bl, pk.row_ld, pk.enabled, pk.do_tick = u.K, u.Bl, u.row_ld, 1, 1
+        pk.beta1, pk.beta2, pk.per_b0, pk.per_b1, pk.total_steps = u.beta1, u.beta2, u.per_b0, u.per_b1, u.total_steps
+        self.packed_direct[name] = pk
+        self.packed_unpack.pop(name, None)
+        self._graphs = {k: v for k, v in self._graphs.items() if not k.startswith(name)}
+        self._segments_cache = {k: v for k, v in self._segments_cache.items() if not k.startswith(name)}
+
+    # --------------------------------------------------------------- draw ahead
+    def attach_replay(self, replay) -> None:
+        super().attach_replay(replay)
+        self._ahead = None
+
+    def update_from_replay(self) -> torch.Tensor:
+        """With uniform replay the batches of the next ``sample_ahead`` updates are drawn by ONE
+        kernel launch (same RNG stream positions, hence the same rows, as drawing them one
+        update at a time) and the phase kernels read them in place: no per-update sampling
+        kernel.  Prioritised replay keeps the draw inside every update, so that it sees the
+        priorities the previous update wrote."""
+        ahead = getattr(self, "_ahead", None)
+        if ahead is None and self.replay is not None and not self.replay.prioritized and self.grad_sync is None \
+                and int(self.cfg.get("sample_ahead", 8)) > 1:
+            from ..parallel.comm import LocalComm
+            from ..parallel.replicated import ReplicatedDP
+            ahead = self._ahead = ReplicatedDP(self, self.replay, LocalComm(), self.B,
+                                               int(self.cfg.get("sample_ahead", 8)), reseed=False)
+        if ahead is not None and self.grad_sync is None:
+            return ahead.update()
+        return super().update_from_replay()
+
     # ------------------------------------------------------------------ shadows
     def refresh_shadows(self) -> None:
         refresh_shadows(self.online.flat.detach(), self.shadow_online, self.layout, self.sl)
@@ -199,10 +239,12 @@ class HipCoreBf16(HipCore):
             elif source == "external":
                 H._check(H.lib().d4pg_tick(st, b1, b2, cfg["priority_beta_start"], cfg["priority_beta_end"],
                                            int(cfg["num_steps_train"]), H.stream_ptr()), "d4pg_tick")
-            else:       # a registered packed batch buffer: unpack it (this also ticks)
+            elif source in self.packed_unpack:      # a registered packed batch buffer: unpack it (this also ticks)
                 H.launch("d4pg_batch_unpack", self.packed_unpack[source])
             a = H.CriticPhaseArgs()
             a.d = dims
+            if source in self.packed_direct:        # rows are read in place; the kernel ticks
+                a.pk = self.packed_direct[source]
             a.sa, a.s2 = self.sa.data_ptr(), self.s2a2.data_ptr()
             a.reward, a.done, a.gamma = self.reward.data_ptr(), self.done.data_ptr(), self.gamma.data_ptr()
             a.weights = self.weights.data_ptr()
@@ -227,6 +269,10 @@ class HipCoreBf16(HipCore):
             a = H.ActorPhaseArgs()
             a.d = dims
             a.s = self.s_pi.data_ptr()
+            if source in self.packed_direct:
+                pk = H.PackedIn.from_buffer_copy(self.packed_direct[source])
+                pk.do_tick = 0
+                a.pk = pk
             for i in range(3):
                 a.af[i] = self._lw(SP, sl.actor[i], P, al[i])
                 a.cf[i] = self._lw(SP, sl.critic[i], P, cl[i])

@@ -165,16 +165,23 @@ class PhaseDims(C.Structure):
                 ("min_value", C.c_float), ("max_value", C.c_float)]
 
 
+class PackedIn(C.Structure):
+    _fields_ = [("in0", vp), ("in1", vp), ("st", vp), ("step0", C.c_longlong),
+                ("K", C.c_int), ("Bl", C.c_int), ("row_ld", C.c_int), ("enabled", C.c_int), ("do_tick", C.c_int),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("per_b0", C.c_float), ("per_b1", C.c_float),
+                ("pad_", C.c_int), ("total_steps", C.c_longlong)]
+
+
 class CriticPhaseArgs(C.Structure):
     _fields_ = [("d", PhaseDims), ("sa", vp), ("s2", vp), ("reward", vp), ("done", vp), ("gamma", vp),
-                ("weights", vp), ("ta", LayerW * 3), ("tc", LayerW * 3), ("cf", LayerW * 3),
+                ("weights", vp), ("pk", PackedIn), ("ta", LayerW * 3), ("tc", LayerW * 3), ("cf", LayerW * 3),
                 ("cb3", LayerW), ("cb2", LayerW),
                 ("saT", vp), ("h1T", vp), ("h2T", vp), ("dlT", vp), ("dh2T", vp), ("dh1T", vp),
                 ("per_loss", vp), ("priority", vp)]
 
 
 class ActorPhaseArgs(C.Structure):
-    _fields_ = [("d", PhaseDims), ("s", vp), ("af", LayerW * 3), ("cf", LayerW * 3),
+    _fields_ = [("d", PhaseDims), ("s", vp), ("pk", PackedIn), ("af", LayerW * 3), ("cf", LayerW * 3),
                 ("cb3", LayerW), ("cb2", LayerW), ("cb1", LayerW), ("ab3", LayerW), ("ab2", LayerW),
                 ("sT", vp), ("h1T", vp), ("h2T", vp), ("daT", vp), ("dh2T", vp), ("dh1T", vp), ("q_val", vp),
                 ("tree", TreeUpdateArgs)]

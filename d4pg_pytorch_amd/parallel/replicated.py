@@ -35,7 +35,7 @@ from .comm import Comm
 
 
 class ReplicatedDP:
-    def __init__(self, core, replay, comm: Comm, local_batch: int, chunk: int = 8):
+    def __init__(self, core, replay, comm: Comm, local_batch: int, chunk: int = 8, reseed: bool = True):
         assert core.device.type == "cuda", "replicated data parallelism runs on the HIP learner cores"
         self.core, self.replay, self.comm = core, replay, comm
         self.world, self.rank = int(comm.world), int(comm.rank)
@@ -52,15 +52,19 @@ class ReplicatedDP:
         self.side = torch.cuda.Stream(device=dev)
         self.drawn = [torch.cuda.Event() for _ in range(2)]      # chunk drawn    (main stream)
         self.ready = [torch.cuda.Event() for _ in range(2)]      # chunk gathered (side stream)
-        # identical replicas, different sampling streams
-        with torch.no_grad():
-            for t in (core.online.flat, core.target.flat, core.adam_m, core.adam_v):
-                comm.broadcast_(t.data if hasattr(t, "data") else t, src=0)
-        core._after_load()
-        st = core.read_dev_state()
-        core._write_dev_state(step=core.step, seed=(st.seed + 0x9E3779B97F4A7C15 * (self.rank + 1)), keep_replay=True)
+        if self.world > 1:
+            # identical replicas
+            with torch.no_grad():
+                for t in (core.online.flat, core.target.flat, core.adam_m, core.adam_v):
+                    comm.broadcast_(t.data if hasattr(t, "data") else t, src=0)
+            core._after_load()
+        if reseed:                   # a sampling stream of its own for every rank
+            st = core.read_dev_state()
+            core._write_dev_state(step=core.step, seed=(st.seed + 0x9E3779B97F4A7C15 * (self.rank + 1)),
+                                  keep_replay=True)
         core.grad_sync = None
-        core.attach_replay(replay)
+        if core.replay is not replay:
+            core.attach_replay(replay)
         self.step0 = int(core.step)
         self.n = 0                   # updates made through this driver
         self._sample_args = [replay.sample_rows_args(self.local[p], self.Bl, self.K) for p in range(2)]
@@ -68,8 +72,11 @@ class ReplicatedDP:
         if replay.prioritized:       # the rank that owns a row writes its priority back
             sl = slice(self.rank * self.Bl, (self.rank + 1) * self.Bl)
             prio_args = replay.priority_update_args(core.idx[sl], core.prio[sl], self.Bl)
-        # unpack + update + priority write-back: ONE captured graph serves every update
-        core.register_packed("gathered", self.bufs[0], self.bufs[1], replay.row_ld, self.Bl, self.K, prio_args)
+        # [unpack +] update [+ priority write-back]: ONE captured graph serves every update
+        if core.supports_direct_input and not replay.prioritized:
+            core.register_direct("gathered", self.bufs[0], self.bufs[1], replay.row_ld, self.Bl, self.K)
+        else:
+            core.register_packed("gathered", self.bufs[0], self.bufs[1], replay.row_ld, self.Bl, self.K, prio_args)
 
     # ------------------------------------------------------------------ prefetch
     def _draw_chunk(self, c: int) -> None:

@@ -32,33 +32,40 @@ def _rows(rp, n, seed):
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp32"])
 def test_world_one_reproduces_the_plain_replay_path(dtype):
+    """plain: one sampling kernel inside every update.  ahead: the core's own draw-ahead path
+    (bf16 + uniform replay: 8 batches per sampling launch, rows read in place by the phase
+    kernels).  replicated: the data-parallel driver over a world of one.  Same RNG stream
+    positions -> same rows -> bit-identical parameters."""
     from d4pg_pytorch_amd.models.core import build_core
     from d4pg_pytorch_amd.parallel.comm import LocalComm
     from d4pg_pytorch_amd.parallel.replicated import attach_replicated
     from d4pg_pytorch_amd.replay.hbm_replay import HbmReplay
-    cfg = _cfg(256, dtype=dtype)
-    outs = []
-    for mode in ("plain", "replicated"):
+    outs = {}
+    for mode in ("plain", "ahead", "replicated"):
+        cfg = dict(_cfg(256, dtype=dtype), sample_ahead=1 if mode == "plain" else 8)
         core = build_core(cfg, "cuda")
         rp = HbmReplay(cfg, "cuda", core.dev_state)
         rp.insert(_rows(rp, 20_000, 1))
-        if mode == "plain":
+        if mode == "replicated":
+            dp = attach_replicated(core, rp, LocalComm(), chunk=4)
+            for _ in range(12):
+                dp.update()
+            assert dp.check_consistency() == 0.0
+        else:
             core.attach_replay(rp)
             st = core.read_dev_state()
             core._write_dev_state(step=0, seed=st.seed + GOLD, keep_replay=True)     # the stream rank 0 samples from
             for _ in range(12):
                 core.update_from_replay()
-        else:
-            dp = attach_replicated(core, rp, LocalComm())
-            for _ in range(12):
-                dp.update()
-            assert dp.check_consistency() == 0.0
+            if dtype == "bf16":
+                assert (core._ahead is not None) == (mode == "ahead")
         torch.cuda.synchronize()
         m = core.read_metrics()
         assert m["count"] == 12 and np.isfinite(m["value_loss"])
-        outs.append((core.online.flat.clone(), core.target.flat.clone(), core.idx.clone()))
-    assert torch.equal(outs[0][2], outs[1][2])            # same rows drawn
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        assert core.read_dev_state().step_done == 12
+        outs[mode] = (core.online.flat.clone(), core.target.flat.clone())
+    for mode in ("ahead", "replicated"):
+        assert torch.equal(outs["plain"][0], outs[mode][0]) and torch.equal(outs["plain"][1], outs[mode][1]), mode
 
 
 @pytest.mark.parametrize("per", [0, 1])
