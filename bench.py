@@ -133,14 +133,23 @@ def main() -> None:
             n = min(chunk, n_fill - off)
             replay.insert(synthetic_rows(n, S, A, replay.row_ld, gamma_n, device, seed=1000 * (rank + 1) + off))
 
-    def timed(one_step):
-        for _ in range(args.warmup):
-            one_step()
+    def timed(one_step, many=None):
+        """``one_step()`` makes one update; ``many(n)`` makes up to n and returns the count (whole
+        drawn-ahead chunks of updates are one graph replay).  Exactly ``warmup`` then exactly
+        ``steps`` updates are made."""
+        def run(total):
+            done = 0
+            while done < total:
+                if many is not None:
+                    done += many(total - done)
+                else:
+                    one_step()
+                    done += 1
+        run(args.warmup)
         comm.barrier()
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            one_step()
+        run(args.steps)
         comm.barrier()
         torch.cuda.synchronize(device)
         return comm.all_reduce_max_scalar(time.perf_counter() - t0)
@@ -173,14 +182,14 @@ def main() -> None:
             core.attach_replay(replay)
             attach_data_parallel(core, comm)
             fill(replay)
-            return core, timed(core.update_from_replay)
+            return core, timed(core.update_from_replay, getattr(core, "update_from_replay_many", None))
 
         def run_replicated():
             core = build_core(dict(cfg, batch_size=args.batch * world), device)
             replay = HbmReplay(cfg, device, core.dev_state)
             fill(replay)
             dp = attach_replicated(core, replay, comm, args.batch)
-            t = timed(dp.update)
+            t = timed(dp.update, dp.update_many)
             drift = dp.check_consistency()
             assert drift == 0.0, f"learner replicas diverged (checksum difference {drift})"
             return core, t

@@ -307,22 +307,30 @@ class HipCore(CoreBase):
             self._segments_cache[source] = self._build_segments(source)
         return self._segments_cache[source]
 
-    def _run(self, source: str) -> None:
+    def _run(self, source: str, reps: int = 1) -> None:
+        """Enqueue ``reps`` consecutive updates from ``source``.  Without gradient exchange they
+        are ONE graph (a graph launch costs ~8 us of idle GPU between two replays, so a source
+        that holds several batches is replayed several updates at a time)."""
         segs = self._segments(source)
         sync = self.grad_sync
         lay = self.layout
-        if not self.use_graph:
-            segs[0]()
-            if sync is not None:
-                sync(self.grad[lay.critic.base: lay.critic.base + lay.critic.numel])
-            segs[1]()
-            if sync is not None:
-                sync(self.grad[lay.actor.base: lay.actor.base + lay.actor.numel])
-            segs[2]()
+        if reps > 1 and sync is not None and self.use_graph:
+            for _ in range(reps):          # gradient exchange between the graph segments: one update at a time
+                self._run(source, 1)
             return
-        key = source + ("/dp" if sync is not None else "")
+        if not self.use_graph:
+            for _ in range(reps):
+                segs[0]()
+                if sync is not None:
+                    sync(self.grad[lay.critic.base: lay.critic.base + lay.critic.numel])
+                segs[1]()
+                if sync is not None:
+                    sync(self.grad[lay.actor.base: lay.actor.base + lay.actor.numel])
+                segs[2]()
+            return
+        key = source + ("/dp" if sync is not None else "") + (f"/x{reps}" if reps > 1 else "")
         if key not in self._graphs:
-            self._graphs[key] = self._capture(segs, fused=sync is None)
+            self._graphs[key] = self._capture(segs, fused=sync is None, reps=reps)
         graphs = self._graphs[key]
         if sync is None:
             graphs[0].replay()
@@ -333,7 +341,7 @@ class HipCore(CoreBase):
             sync(self.grad[lay.actor.base: lay.actor.base + lay.actor.numel])
             graphs[2].replay()
 
-    def _capture(self, segs, fused: bool):
+    def _capture(self, segs, fused: bool, reps: int = 1):
         """Warm up once eagerly (module loading, allocator) on a side stream,
         restore the state it touched, then capture."""
         snap = self._snapshot()
@@ -345,7 +353,7 @@ class HipCore(CoreBase):
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize(self.device)
         self._restore(snap)
-        groups = [segs] if fused else [[f] for f in segs]
+        groups = [list(segs) * reps] if fused else [[f] for f in segs]
         graphs = []
         # No garbage collection while a stream is capturing: a collected tensor or event is
         # released through hipFree / hipEventDestroy, which is illegal during capture and
@@ -455,11 +463,18 @@ class HipCore(CoreBase):
 
     supports_direct_input = False     # the fused bf16 pipeline reads packed chunk rows in place
 
-    def update_from_source(self, name: str) -> torch.Tensor:
-        """One update on the registered packed batch source ``name``; returns the priorities."""
-        self._run(name)
-        self.step += 1
+    def update_from_source(self, name: str, reps: int = 1) -> torch.Tensor:
+        """``reps`` consecutive updates on the registered packed batch source ``name`` (which must
+        hold that many batches from the current step on); returns the last priorities."""
+        self._run(name, reps)
+        self.step += reps
         return self.prio
+
+    def update_from_replay_many(self, n: int) -> int:
+        """Up to ``n`` updates from the attached replay in one call; returns how many were made.
+        The base implementation makes one."""
+        self.update_from_replay()
+        return 1
 
     def update_from_packed(self, packed: torch.Tensor, row_ld: int) -> torch.Tensor:
         """One update on an arbitrary packed batch ``[B, row_ld + 4]`` (the rows are copied into a

@@ -110,6 +110,14 @@ class HipCoreBf16(HipCore):
             return ahead.update()
         return super().update_from_replay()
 
+    def update_from_replay_many(self, n: int) -> int:
+        """Up to ``n`` updates in one call: a whole drawn-ahead chunk of batches is ONE graph replay."""
+        ahead = getattr(self, "_ahead", None)
+        if ahead is None:
+            self.update_from_replay()      # creates the draw-ahead driver when it applies
+            return 1
+        return ahead.update_many(n)
+
     # ------------------------------------------------------------------ shadows
     def refresh_shadows(self) -> None:
         refresh_shadows(self.online.flat.detach(), self.shadow_online, self.layout, self.sl)

@@ -153,18 +153,25 @@ class Learner:
         name = "checkpoint_final.pt" if final else f"checkpoint_{self.core.step}.pt"
         return save_learner_bundle(os.path.join(self.log_dir, "learner", name), self.core.state_bundle(), self.config)
 
-    def _after_update(self, extra_fn=None) -> None:
+    def _after_update(self, extra_fn=None, prev_step: Optional[int] = None) -> None:
+        """Periodic work after one call that advanced the learner from ``prev_step`` to
+        ``core.step`` (several updates when a whole chunk was replayed as one graph): every
+        interval whose multiple was reached or crossed fires once."""
         cfg, step = self.config, self.core.step
+        prev = step - 1 if prev_step is None else prev_step
+
+        def crossed(interval: int) -> bool:
+            return interval > 0 and step // interval != prev // interval
+
         self.ctrl.store(ControlBlock.UPDATE_STEP, step)
-        if step % int(cfg["weight_publish_interval"]) == 0:
+        if crossed(int(cfg["weight_publish_interval"])):
             self.publish_weights()
-        if step % int(cfg["metrics_interval"]) == 0:
+        if crossed(int(cfg["metrics_interval"])):
             self._log_metrics(extra_fn() if extra_fn else None)
             self.ctrl.heartbeat(0, int(time.time() * 1000))
-        if step % 1000 == 0 and self.rank == 0:
-            print("Training step ", step, flush=True)
-        ci = int(cfg.get("learner_checkpoint_interval") or 0)
-        if ci > 0 and step % ci == 0:
+        if crossed(1000) and self.rank == 0:
+            print("Training step ", step - step % 1000, flush=True)
+        if crossed(int(cfg.get("learner_checkpoint_interval") or 0)):
             self._checkpoint()
 
     def _throttle(self) -> bool:
@@ -201,6 +208,11 @@ class Learner:
         ingest_every = max(1, int(cfg.get("ingest_interval", 32)))     # updates between two ring drains
         self.publish_weights()
         ctrl.store(ControlBlock.LEARNER_ALIVE, 1)
+        last_ingest = core.step
+        if dp is not None:
+            burst = dp.update_many
+        else:
+            burst = getattr(core, "update_from_replay_many", None) or (lambda n: core.update_from_replay() and 1)
 
         def extra():
             return {"data_struct/replay_buffer": float(len(replay)),
@@ -217,14 +229,13 @@ class Learner:
                     time.sleep(0.0005)
                 ctrl.heartbeat(0, int(time.time() * 1000))
                 continue
-            if core.step % ingest_every == 0:
+            prev = core.step
+            if prev % ingest_every == 0 or prev // ingest_every != last_ingest // ingest_every:
+                last_ingest = prev
                 if ingest.poll() and dp is not None:
                     dp.mark_inserted()
-            if dp is not None:
-                dp.update()
-            else:
-                core.update_from_replay()
-            self._after_update(extra)
+            burst(self.num_train_steps - prev)       # one update, or a whole drawn-ahead chunk as one graph
+            self._after_update(extra, prev)
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
         if dp is not None:

@@ -116,6 +116,24 @@ class ReplicatedDP:
         self.n += 1
         return prio
 
+    def update_many(self, n: int) -> int:
+        """Up to ``n`` updates; returns how many were made.  At a chunk boundary with at least a
+        whole chunk to go, the K updates that consume the chunk are ONE graph replay."""
+        K = self.K
+        if n < K or self.n % K != 0 or K == 1:
+            self.update()
+            return 1
+        core, c = self.core, self.n // K
+        if not (c == 0 and getattr(self, "_primed_by_inspection", False)):
+            if c == 0:
+                self._draw_chunk(0)
+            self._draw_chunk(c + 1)
+        if self.world > 1:
+            torch.cuda.current_stream(core.device).wait_event(self.ready[c & 1])
+        core.update_from_source("gathered", K)
+        self.n += K
+        return K
+
     def current_batch(self) -> torch.Tensor:
         """The packed global batch ``[world * Bl, W]`` the NEXT ``update()`` will consume (testing /
         inspection; synchronises)."""

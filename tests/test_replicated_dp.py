@@ -41,8 +41,8 @@ def test_world_one_reproduces_the_plain_replay_path(dtype):
     from d4pg_pytorch_amd.parallel.replicated import attach_replicated
     from d4pg_pytorch_amd.replay.hbm_replay import HbmReplay
     outs = {}
-    for mode in ("plain", "ahead", "replicated"):
-        cfg = dict(_cfg(256, dtype=dtype), sample_ahead=1 if mode == "plain" else 8)
+    for mode in ("plain", "ahead", "many", "replicated"):
+        cfg = dict(_cfg(256, dtype=dtype), sample_ahead=1 if mode == "plain" else 4)
         core = build_core(cfg, "cuda")
         rp = HbmReplay(cfg, "cuda", core.dev_state)
         rp.insert(_rows(rp, 20_000, 1))
@@ -55,16 +55,22 @@ def test_world_one_reproduces_the_plain_replay_path(dtype):
             core.attach_replay(rp)
             st = core.read_dev_state()
             core._write_dev_state(step=0, seed=st.seed + GOLD, keep_replay=True)     # the stream rank 0 samples from
-            for _ in range(12):
-                core.update_from_replay()
+            if mode == "many":        # whole chunks of updates as one graph replay, plus a remainder
+                done = 0
+                while done < 12:
+                    done += core.update_from_replay_many(12 - done)
+                assert done == 12 and core.step == 12
+            else:
+                for _ in range(12):
+                    core.update_from_replay()
             if dtype == "bf16":
-                assert (core._ahead is not None) == (mode == "ahead")
+                assert (core._ahead is not None) == (mode != "plain")
         torch.cuda.synchronize()
         m = core.read_metrics()
         assert m["count"] == 12 and np.isfinite(m["value_loss"])
         assert core.read_dev_state().step_done == 12
         outs[mode] = (core.online.flat.clone(), core.target.flat.clone())
-    for mode in ("ahead", "replicated"):
+    for mode in ("ahead", "many", "replicated"):
         assert torch.equal(outs["plain"][0], outs[mode][0]) and torch.equal(outs["plain"][1], outs[mode][1]), mode
 
 
