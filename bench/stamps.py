@@ -23,7 +23,7 @@ from d4pg_pytorch_amd.ops import hip as H  # noqa: E402
 from d4pg_pytorch_amd.replay.hbm_replay import HbmReplay  # noqa: E402
 
 CRITIC = ["zero", "load", "ta1", "ta2", "ta3", "tc1", "tc2", "tc3+cf1", "cf2", "cf3", "loss", "cb3", "cb2"]
-ACTOR = ["zero", "load", "af1", "af2", "af3", "cf1", "cf2", "cf3", "loss", "cb3", "cb2", "cb1", "ab3", "ab2"]
+ACTOR = ["prologue", "cf1", "cf2", "cf3", "loss", "cb3", "cb2", "cb1", "ab3", "ab2"]
 
 
 def main():

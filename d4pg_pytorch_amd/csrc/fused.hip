@@ -390,6 +390,22 @@ struct PhaseDims {
     float min_value, max_value;   // scalar-critic target clamp
 };
 
+// The online actor's forward pass a = pi(s) does not depend on the critic update, so it does
+// not belong on the critical path critic phase -> critic optimiser -> actor phase: it runs in
+// B / M EXTRA workgroups of the critic phase launch (on compute units that would idle) and
+// hands its row tiles to the actor phase through global memory.
+struct ActorFwd {
+    LayerW af[3];          // online actor, forward
+    const float* s;        // [B, ldx_in] state (action columns ignored) unless the batch is packed
+    __bf16* sT;            // transposed stashes for the actor's weight gradients, [rows16][Bp]
+    __bf16* h1T;
+    __bf16* h2T;
+    __bf16* g_xin;         // [B][ldx]  s | pi(s) | 0   (LDS tile images, row-major, read back by the actor phase)
+    __bf16* g_h1;          // [B][ldh]
+    __bf16* g_h2;          // [B][ldh]
+    float* g_pi;           // [B][16 * ceil(A / 16)]  pi(s) in fp32 (for tanh')
+};
+
 struct CriticPhaseArgs {
     PhaseDims d;
     const float* sa;       // [B, ldx_in]  state | action
@@ -412,6 +428,7 @@ struct CriticPhaseArgs {
     __bf16* dh1T;
     float* per_loss;
     float* priority;
+    ActorFwd fwd;
 };
 
 // zero `bytes` (multiple of 16) of LDS
@@ -428,6 +445,12 @@ __device__ __forceinline__ void zero_tail(__bf16* buf, int ld, int M, int c0) {
         const int r = i / chunks, c = i - r * chunks;
         *reinterpret_cast<f32x4*>(buf + r * ld + a0 + 8 * c) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+}
+
+// flat copy of `bytes` (multiple of 16, both sides 16-byte aligned)
+__device__ __forceinline__ void copy16(void* dst, const void* src, int bytes) {
+    for (int i = threadIdx.x * 16; i < bytes; i += blockDim.x * 16)
+        *reinterpret_cast<f32x4*>((char*)dst + i) = *reinterpret_cast<const f32x4*>((const char*)src + i);
 }
 
 // Load `ncols` fp32 columns of M batch rows into a bf16 LDS tile whose remaining columns (up to
@@ -499,6 +522,57 @@ __device__ __forceinline__ void critic_rows(const CriticPhaseArgs& a, int row0, 
 }
 
 template <int MT, int KSH, int KSN>
+__device__ __forceinline__ void actor_forward_role(const CriticPhaseArgs& a, int row0, char* smem) {
+    constexpr int M = 16 * MT;
+    const PhaseDims& d = a.d;
+    const ActorFwd& f = a.fwd;
+    Chain<MT, KSH, KSN> ch;
+    ch.prefetch_n(f.af[0]);
+    int off = 0;
+    auto carve = [&](int bytes) { char* p = smem + off; off += (bytes + 15) & ~15; return p; };
+    const int ldpi = 16 * ((d.A + 15) / 16);
+    __bf16* xin = (__bf16*)carve(M * d.ldx * 2);    // [s | pi(s)]
+    __bf16* bufA = (__bf16*)carve(M * d.ldh * 2);   // h1
+    __bf16* bufB = (__bf16*)carve(M * d.ldh * 2);   // h2
+    float* pi = (float*)carve(M * ldpi * 4);
+    zero_tail(bufA, d.ldh, M, d.H);
+    zero_tail(bufB, d.ldh, M, d.H);
+    zero_block(pi, M * ldpi * 4);
+    load_input(a.pk.enabled ? packed_src(a.pk, 0) : plain_src(f.s, d.ldx_in, d.B), row0, M, d.S, xin, d.ldx, f.sT,
+               d.Bp);
+    __syncthreads();
+    ch.narrow(xin, d.ldx, f.af[0], [=](int r0, int col, f32x4 v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        put_lds4(bufA, d.ldh, r0, col, v);
+        put_stash4(f.h1T, d.Bp, col, row0 + r0, v);
+    }, [&] { ch.template prefetch_h<0>(f.af[1]); });
+    __syncthreads();
+    copy16(f.g_h1 + (size_t)row0 * d.ldh, bufA, M * d.ldh * 2);
+    ch.template hidden<0>(bufA, d.ldh, f.af[1], [=](int r0, int col, f32x4 v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        put_lds4(bufB, d.ldh, r0, col, v);
+        put_stash4(f.h2T, d.Bp, col, row0 + r0, v);
+    }, [&] { ch.template prefetch_h<1>(f.af[2]); });
+    __syncthreads();
+    copy16(f.g_h2 + (size_t)row0 * d.ldh, bufB, M * d.ldh * 2);
+    ch.template hidden<1>(bufB, d.ldh, f.af[2], [=](int r0, int col, f32x4 v) {
+        if (col < d.A) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = fast_tanh(v[r]);
+                pi[(r0 + r) * ldpi + col] = v[r];
+            }
+            put_lds4(xin, d.ldx, r0, d.S + col, v);
+        }
+    }, [] {});
+    __syncthreads();
+    copy16(f.g_xin + (size_t)row0 * d.ldx, xin, M * d.ldx * 2);
+    copy16(f.g_pi + (size_t)row0 * ldpi, pi, M * ldpi * 4);
+}
+
+template <int MT, int KSH, int KSN>
 __global__ __launch_bounds__(64 * NW) void critic_phase_kernel(const CriticPhaseArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int M = 16 * MT;
@@ -506,6 +580,10 @@ __global__ __launch_bounds__(64 * NW) void critic_phase_kernel(const CriticPhase
     const int row0 = blockIdx.x * M;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (row0 >= d.B) {         // the second half of the grid: actor forward
+        actor_forward_role<MT, KSH, KSN>(a, row0 - d.B, smem);
+        return;
+    }
     STAMP(0, 31);
     Chain<MT, KSH, KSN> ch;
     ch.prefetch_n(a.ta[0]);
@@ -656,16 +734,15 @@ __global__ __launch_bounds__(64 * NW) void critic_phase_kernel(const CriticPhase
 // ---------------------------------------------------------------------------------------
 struct ActorPhaseArgs {
     PhaseDims d;
-    const float* s;        // [B, ldx_in] state (action columns ignored)
-    PackedIn pk;           // pk.enabled: states come from the packed chunk buffers instead
-    LayerW af[3];          // online actor, forward
+    // row tiles of the actor forward pass, produced by the extra workgroups of the critic phase
+    const __bf16* g_xin;   // [B][ldx]  s | pi(s) | 0
+    const __bf16* g_h1;    // [B][ldh]
+    const __bf16* g_h2;    // [B][ldh]
+    const float* g_pi;     // [B][16 * ceil(A / 16)]
     LayerW cf[3];          // online critic (already updated), forward
     LayerW cb3, cb2, cb1;  // critic backward: layers 3, 2 and the action columns of layer 1
     LayerW ab3, ab2;       // actor backward: layers 3 and 2
-    __bf16* sT;            // transposed stashes [rows16][Bp]
-    __bf16* h1T;
-    __bf16* h2T;
-    __bf16* daT;
+    __bf16* daT;           // transposed stashes [rows16][Bp]
     __bf16* dh2T;
     __bf16* dh1T;
     float* q_val;          // [B]
@@ -717,9 +794,10 @@ __global__ __launch_bounds__(64 * NW) void actor_phase_kernel(const ActorPhaseAr
     }
     STAMP(1, 31);
     Chain<MT, KSH, KSN> ch;
-    ch.prefetch_n(a.af[0]);
+    ch.prefetch_n(a.cf[0]);
     int off = 0;
     auto carve = [&](int bytes) { char* p = smem + off; off += (bytes + 15) & ~15; return p; };
+    const int ldpi = 16 * ((d.A + 15) / 16);
     __bf16* xin = (__bf16*)carve(M * d.ldx * 2);    // [s | pi(s)]
     __bf16* bufA = (__bf16*)carve(M * d.ldh * 2);   // h1 actor
     __bf16* bufB = (__bf16*)carve(M * d.ldh * 2);   // h2 actor, then dh2 actor in place
@@ -728,47 +806,17 @@ __global__ __launch_bounds__(64 * NW) void actor_phase_kernel(const ActorPhaseAr
     __bf16* dlg = (__bf16*)carve(M * d.ldd * 2);
     __bf16* dab = (__bf16*)carve(M * d.lda_ * 2);
     float* lg_o = (float*)carve(M * d.nop * 4);
-    float* pi = (float*)carve(M * 16 * ((d.A + 15) / 16) * 4);
-    const int ldpi = 16 * ((d.A + 15) / 16);
+    float* pi = (float*)carve(M * ldpi * 4);
+    // ---- the actor forward pass of this tile was made alongside the critic phase ----
+    copy16(xin, a.g_xin + (size_t)row0 * d.ldx, M * d.ldx * 2);
+    copy16(pi, a.g_pi + (size_t)row0 * ldpi, M * ldpi * 4);
+    copy16(bufA, a.g_h1 + (size_t)row0 * d.ldh, M * d.ldh * 2);
+    copy16(bufB, a.g_h2 + (size_t)row0 * d.ldh, M * d.ldh * 2);
     zero_block(dlg, M * (d.ldd + d.lda_) * 2);      // dlg and dab are adjacent
-    zero_tail(bufA, d.ldh, M, d.H);
-    zero_tail(bufB, d.ldh, M, d.H);
     zero_tail(bufC, d.ldh, M, d.H);
     zero_tail(bufD, d.ldh, M, d.H);
+    __syncthreads();
     STAMP(1, 0);
-    load_input(a.pk.enabled ? packed_src(a.pk, 0) : plain_src(a.s, d.ldx_in, d.B), row0, M, d.S, xin, d.ldx, a.sT,
-               d.Bp);
-    __syncthreads();
-    STAMP(1, 1);
-    // ---- actor forward ----
-    ch.narrow(xin, d.ldx, a.af[0], [=](int r0, int col, f32x4 v) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-        put_lds4(bufA, d.ldh, r0, col, v);
-        put_stash4(a.h1T, d.Bp, col, row0 + r0, v);
-    }, [&] { ch.template prefetch_h<0>(a.af[1]); });
-    __syncthreads();
-    STAMP(1, 2);
-    ch.template hidden<0>(bufA, d.ldh, a.af[1], [=](int r0, int col, f32x4 v) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-        put_lds4(bufB, d.ldh, r0, col, v);
-        put_stash4(a.h2T, d.Bp, col, row0 + r0, v);
-    }, [&] { ch.template prefetch_h<1>(a.af[2]); });
-    __syncthreads();
-    STAMP(1, 3);
-    ch.template hidden<1>(bufB, d.ldh, a.af[2], [=](int r0, int col, f32x4 v) {
-        if (col < d.A) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[r] = fast_tanh(v[r]);
-                pi[(r0 + r) * ldpi + col] = v[r];
-            }
-            put_lds4(xin, d.ldx, r0, d.S + col, v);
-        }
-    }, [&] { ch.prefetch_n(a.cf[0]); });
-    __syncthreads();
-    STAMP(1, 4);
     // ---- critic forward at (s, pi(s)) ----
     auto relu_to = [&](__bf16* buf) {
         return [=](int r0, int col, f32x4 v) {
@@ -779,10 +827,10 @@ __global__ __launch_bounds__(64 * NW) void actor_phase_kernel(const ActorPhaseAr
     };
     ch.narrow(xin, d.ldx, a.cf[0], relu_to(bufC), [&] { ch.template prefetch_h<0>(a.cf[1]); });
     __syncthreads();
-    STAMP(1, 5);
+    STAMP(1, 1);
     ch.template hidden<0>(bufC, d.ldh, a.cf[1], relu_to(bufD), [&] { ch.template prefetch_h<1>(a.cf[2]); });
     __syncthreads();
-    STAMP(1, 6);
+    STAMP(1, 2);
     ch.template hidden<1>(bufD, d.ldh, a.cf[2], [=](int r0, int col, f32x4 v) {
         if (col < d.nop) {
 #pragma unroll
@@ -790,14 +838,14 @@ __global__ __launch_bounds__(64 * NW) void actor_phase_kernel(const ActorPhaseAr
         }
     }, [&] { ch.prefetch_n(a.cb3); });
     __syncthreads();
-    STAMP(1, 7);
+    STAMP(1, 3);
     // ---- actor loss: -mean Q ----
     if (d.distributional && d.NO <= 64)
         actor_rows<1, M>(a, row0, lane, wave, lg_o, dlg);
     else
         actor_rows<4, M>(a, row0, lane, wave, lg_o, dlg);
     __syncthreads();
-    STAMP(1, 8);
+    STAMP(1, 4);
     // ---- critic backward (dX only) down to the action ----
     ch.narrow(dlg, d.ldd, a.cb3, [=](int r0, int col, f32x4 v) {
 #pragma unroll
@@ -805,14 +853,14 @@ __global__ __launch_bounds__(64 * NW) void actor_phase_kernel(const ActorPhaseAr
         put_lds4(bufD, d.ldh, r0, col, v);
     }, [&] { ch.template prefetch_h<0>(a.cb2); });
     __syncthreads();
-    STAMP(1, 9);
+    STAMP(1, 5);
     ch.template hidden<0>(bufD, d.ldh, a.cb2, [=](int r0, int col, f32x4 v) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = (float)bufC[(r0 + r) * d.ldh + col] > 0.f ? v[r] : 0.f;
         put_lds4(bufC, d.ldh, r0, col, v);
     }, [&] { ch.template prefetch_h<1>(a.cb1); });
     __syncthreads();
-    STAMP(1, 10);
+    STAMP(1, 6);
     ch.template hidden<1>(bufC, d.ldh, a.cb1, [=](int r0, int col, f32x4 v) {
         if (col < d.A) {
 #pragma unroll
@@ -825,7 +873,7 @@ __global__ __launch_bounds__(64 * NW) void actor_phase_kernel(const ActorPhaseAr
         }
     }, [&] { ch.prefetch_n(a.ab3); });
     __syncthreads();
-    STAMP(1, 11);
+    STAMP(1, 7);
     // ---- actor backward ----
     ch.narrow(dab, d.lda_, a.ab3, [=](int r0, int col, f32x4 v) {
 #pragma unroll
@@ -834,14 +882,14 @@ __global__ __launch_bounds__(64 * NW) void actor_phase_kernel(const ActorPhaseAr
         put_stash4(a.dh2T, d.Bp, col, row0 + r0, v);
     }, [&] { ch.template prefetch_h<0>(a.ab2); });
     __syncthreads();
-    STAMP(1, 12);
+    STAMP(1, 8);
     ch.template hidden<0>(bufB, d.ldh, a.ab2, [=](int r0, int col, f32x4 v) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = (float)bufA[(r0 + r) * d.ldh + col] > 0.f ? v[r] : 0.f;
         put_stash4(a.dh1T, d.Bp, col, row0 + r0, v);
     }, [] {});
     STAMP_SYNC();
-    STAMP(1, 13);
+    STAMP(1, 9);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -932,8 +980,14 @@ D4PG_API int d4pg_critic_phase(const CriticPhaseArgs* a, int mt, hipStream_t str
     for (int i = 1; i < 3; ++i)
         if (check_hidden(a->ta[i], ksh_) || check_hidden(a->tc[i], ksh_) || check_hidden(a->cf[i], ksh_)) return -10;
     if (check_hidden(a->cb2, ksh_)) return -10;
-    const int ksn = max3i(a->cb3.ks, a->ta[0].ks, max3i(a->tc[0].ks, a->cf[0].ks, 0));
-    const int extra_blocks = 0;
+    for (int i = 0; i < 3; ++i)
+        if (check_layer(a->fwd.af[i], kmax)) return -6;
+    if (check_hidden(a->fwd.af[1], ksh_) || check_hidden(a->fwd.af[2], ksh_)) return -10;
+    if (a->fwd.g_xin == nullptr || a->fwd.g_h1 == nullptr || a->fwd.g_h2 == nullptr || a->fwd.g_pi == nullptr ||
+        a->fwd.sT == nullptr || a->fwd.h1T == nullptr || a->fwd.h2T == nullptr)
+        return -14;
+    const int ksn = max3i(a->cb3.ks, a->ta[0].ks, max3i(a->tc[0].ks, a->cf[0].ks, a->fwd.af[0].ks));
+    const int extra_blocks = a->d.B / (mt == 2 ? 32 : 16);      // the actor forward pass rides along
     if (int prc = check_packed(a->pk, a->d)) return prc;
     DISPATCH_PHASE(critic_phase_kernel, phase_lds_bytes_critic)
 }
@@ -942,19 +996,19 @@ D4PG_API int d4pg_actor_phase(const ActorPhaseArgs* a, int mt, hipStream_t strea
     const int kmax = max_k32(a->d);
     const int ksh_ = (a->d.ldh - LDS_PAD) / 32;
     for (int i = 0; i < 3; ++i)
-        if (check_layer(a->af[i], kmax) || check_layer(a->cf[i], kmax)) return -6;
+        if (check_layer(a->cf[i], kmax)) return -6;
     if (check_layer(a->cb3, kmax) || check_layer(a->cb2, kmax) || check_layer(a->cb1, kmax) ||
         check_layer(a->ab3, kmax) || check_layer(a->ab2, kmax))
         return -6;
     for (int i = 1; i < 3; ++i)
-        if (check_hidden(a->af[i], ksh_) || check_hidden(a->cf[i], ksh_)) return -10;
+        if (check_hidden(a->cf[i], ksh_)) return -10;
+    if (a->g_xin == nullptr || a->g_h1 == nullptr || a->g_h2 == nullptr || a->g_pi == nullptr) return -14;
     if (check_hidden(a->cb2, ksh_) || check_hidden(a->cb1, ksh_) || check_hidden(a->ab2, ksh_)) return -10;
-    const int ksn = max3i(a->af[0].ks, a->cf[0].ks, max3i(a->cb3.ks, a->ab3.ks, 0));
+    const int ksn = max3i(a->cf[0].ks, a->cb3.ks, a->ab3.ks);
     if (a->tree.n < 0 || (a->tree.n > 0 && (a->tree.idx == nullptr || a->tree.prio == nullptr ||
                                             a->tree.t.L < 0 || a->tree.t.L > MAXL)))
         return -11;
     const int extra_blocks = a->tree.n > 0 ? 1 : 0;
-    if (int prc = check_packed(a->pk, a->d)) return prc;
     DISPATCH_PHASE(actor_phase_kernel, phase_lds_bytes_actor)
 }
 

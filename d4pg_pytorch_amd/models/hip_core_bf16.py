@@ -55,6 +55,12 @@ class HipCoreBf16(HipCore):
         self.sT, self.a_h1T, self.a_h2T = stash(S), stash(Hd), stash(Hd)
         self.a_daT, self.a_dh2T, self.a_dh1T = stash(A), stash(Hd), stash(Hd)
         self.dims = self._phase_dims()
+        # row tiles of the actor forward pass, handed from the critic phase launch to the actor phase
+        ldpi = 16 * ((A + 15) // 16)
+        self.g_xin = torch.zeros(B, self.dims.ldx, dtype=torch.bfloat16, device=dev)
+        self.g_h1 = torch.zeros(B, self.dims.ldh, dtype=torch.bfloat16, device=dev)
+        self.g_h2 = torch.zeros(B, self.dims.ldh, dtype=torch.bfloat16, device=dev)
+        self.g_pi = torch.zeros(B, ldpi, dtype=torch.float32, device=dev)
         # rows per workgroup: a phase is a latency-bound chain whose length does not depend on the
         # number of workgroups until they outnumber the 256 CUs, so 16-row tiles (more, smaller
         # workgroups) win up to B = 4096; beyond that 32-row tiles halve the weight traffic
@@ -265,6 +271,14 @@ class HipCoreBf16(HipCore):
             a.saT, a.h1T, a.h2T = self.saT.data_ptr(), self.c_h1T.data_ptr(), self.c_h2T.data_ptr()
             a.dlT, a.dh2T, a.dh1T = self.c_dlT.data_ptr(), self.c_dh2T.data_ptr(), self.c_dh1T.data_ptr()
             a.per_loss, a.priority = self.per_loss.data_ptr(), self.prio.data_ptr()
+            # the online actor's forward pass rides along in extra workgroups of this launch
+            f = a.fwd
+            for i in range(3):
+                f.af[i] = self._lw(SP, sl.actor[i], P, al[i])
+            f.s = self.s_pi.data_ptr()
+            f.sT, f.h1T, f.h2T = self.sT.data_ptr(), self.a_h1T.data_ptr(), self.a_h2T.data_ptr()
+            f.g_xin, f.g_h1, f.g_h2, f.g_pi = (self.g_xin.data_ptr(), self.g_h1.data_ptr(), self.g_h2.data_ptr(),
+                                               self.g_pi.data_ptr())
             H._check(H.lib().d4pg_critic_phase(a, self.mt, H.stream_ptr()), "d4pg_critic_phase")
             # the priority write-back rides along with the actor phase (seg_actor)
             self._wgrad([(self.c_dlT, self.c_h2T, cl[2], sl.critic[2]), (self.c_dh2T, self.c_h1T, cl[1], sl.critic[1]),
@@ -276,20 +290,15 @@ class HipCoreBf16(HipCore):
                 H.launch("d4pg_adam_polyak", adam_args(lay.critic, sl.critic, self.lr_critic, 0))
             a = H.ActorPhaseArgs()
             a.d = dims
-            a.s = self.s_pi.data_ptr()
-            if source in self.packed_direct:
-                pk = H.PackedIn.from_buffer_copy(self.packed_direct[source])
-                pk.do_tick = 0
-                a.pk = pk
+            a.g_xin, a.g_h1, a.g_h2, a.g_pi = (self.g_xin.data_ptr(), self.g_h1.data_ptr(), self.g_h2.data_ptr(),
+                                               self.g_pi.data_ptr())
             for i in range(3):
-                a.af[i] = self._lw(SP, sl.actor[i], P, al[i])
                 a.cf[i] = self._lw(SP, sl.critic[i], P, cl[i])
             a.cb3 = self._lw(SP, sl.critic[2], P, cl[2], back=True)
             a.cb2 = self._lw(SP, sl.critic[1], P, cl[1], back=True)
             a.cb1 = self._lw(SP, sl.critic[0], P, cl[0], back=True)
             a.ab3 = self._lw(SP, sl.actor[2], P, al[2], back=True)
             a.ab2 = self._lw(SP, sl.actor[1], P, al[1], back=True)
-            a.sT, a.h1T, a.h2T = self.sT.data_ptr(), self.a_h1T.data_ptr(), self.a_h2T.data_ptr()
             a.daT, a.dh2T, a.dh1T = self.a_daT.data_ptr(), self.a_dh2T.data_ptr(), self.a_dh1T.data_ptr()
             a.q_val = self.q_val.data_ptr()
             if source == "replay" and self.replay.prioritized:

@@ -172,18 +172,24 @@ class PackedIn(C.Structure):
                 ("pad_", C.c_int), ("total_steps", C.c_longlong)]
 
 
+class ActorFwd(C.Structure):
+    _fields_ = [("af", LayerW * 3), ("s", vp), ("sT", vp), ("h1T", vp), ("h2T", vp),
+                ("g_xin", vp), ("g_h1", vp), ("g_h2", vp), ("g_pi", vp)]
+
+
 class CriticPhaseArgs(C.Structure):
     _fields_ = [("d", PhaseDims), ("sa", vp), ("s2", vp), ("reward", vp), ("done", vp), ("gamma", vp),
                 ("weights", vp), ("pk", PackedIn), ("ta", LayerW * 3), ("tc", LayerW * 3), ("cf", LayerW * 3),
                 ("cb3", LayerW), ("cb2", LayerW),
                 ("saT", vp), ("h1T", vp), ("h2T", vp), ("dlT", vp), ("dh2T", vp), ("dh1T", vp),
-                ("per_loss", vp), ("priority", vp)]
+                ("per_loss", vp), ("priority", vp), ("fwd", ActorFwd)]
 
 
 class ActorPhaseArgs(C.Structure):
-    _fields_ = [("d", PhaseDims), ("s", vp), ("pk", PackedIn), ("af", LayerW * 3), ("cf", LayerW * 3),
+    _fields_ = [("d", PhaseDims), ("g_xin", vp), ("g_h1", vp), ("g_h2", vp), ("g_pi", vp),
+                ("cf", LayerW * 3),
                 ("cb3", LayerW), ("cb2", LayerW), ("cb1", LayerW), ("ab3", LayerW), ("ab2", LayerW),
-                ("sT", vp), ("h1T", vp), ("h2T", vp), ("daT", vp), ("dh2T", vp), ("dh1T", vp), ("q_val", vp),
+                ("daT", vp), ("dh2T", vp), ("dh1T", vp), ("q_val", vp),
                 ("tree", TreeUpdateArgs)]
 
 
