@@ -72,57 +72,53 @@ __device__ __forceinline__ void tree_update_body(const TreeUpdateArgs& a) {
     if (lane == 0 && local_max > 0.f)
         atomicMax(reinterpret_cast<unsigned int*>(&a.st->max_priority), __float_as_uint(local_max));
     __syncthreads();
-    // Per level every wave handles TU touched parents at a time: all index loads, then all
-    // 64-wide child loads are issued before the first reduction, so a level costs about two
-    // memory round trips instead of two per parent.
-    // A level with far fewer nodes than the batch has items is recomputed whole (the top level:
-    // 4 nodes for a 1M-row replay) instead of once per item.
-    constexpr int TU = 8;
+    // One THREAD per touched parent: its 64 children are contiguous (256 B of leaves, or 512 B of
+    // fp64 sums + 256 B of minima), so a thread fetches them with 16-byte loads that are all in
+    // flight together and reduces them in registers; a level costs one memory round trip for the
+    // whole batch.  (Duplicate parents are recomputed to the same value.)  A level with far fewer
+    // nodes than the batch has items is recomputed whole (the top level: 4 nodes for 1M rows).
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    const int nthreads = 64 * NWAVES;
     for (int l = 1; l <= a.t.L; ++l) {
-        const bool whole = a.t.n[l] * 8 <= (long long)a.n;
-        const int tasks = whole ? (int)a.t.n[l] : a.n;
-        for (int base = 0; base < tasks; base += NWAVES * TU) {
-            long long g[TU];
-            bool act[TU];
+        const long long nodes = a.t.n[l - 1] >> 6;       // nodes of this level that have children (levels are padded)
+        const bool whole = nodes * 8 <= (long long)a.n;
+        const int tasks = whole ? (int)nodes : a.n;
+        for (int i = tid; i < tasks; i += nthreads) {
+            const long long g = whole ? (long long)i : (a.idx[i] >> (6 * l));
+            double s = 0.0;
+            float m = INFINITY;
+            if (l == 1) {
+                const f32x4* c = reinterpret_cast<const f32x4*>(a.t.leaf + g * 64);
+                f32x4 v[16];
 #pragma unroll
-            for (int u = 0; u < TU; ++u) {
-                const int i = base + wave + NWAVES * u;
-                act[u] = i < tasks;
-                g[u] = 0;
-                if (act[u]) {
-                    if (whole) {
-                        g[u] = i;
-                    } else {
-                        g[u] = a.idx[i] >> (6 * l);
-                        if (i > 0 && (a.idx[i - 1] >> (6 * l)) == g[u]) act[u] = false;   // adjacent duplicate parent
+                for (int k = 0; k < 16; ++k) v[k] = c[k];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        s += (double)v[k][e];
+                        m = fminf(m, v[k][e] > 0.f ? v[k][e] : INFINITY);
                     }
                 }
-            }
-            double sv[TU];
-            float mv[TU];
+            } else {
+                const f64x2* cs = reinterpret_cast<const f64x2*>(a.t.sum[l - 1] + g * 64);
+                const f32x4* cm = reinterpret_cast<const f32x4*>(a.t.mn[l - 1] + g * 64);
+                f32x4 mv[16];
 #pragma unroll
-            for (int u = 0; u < TU; ++u) {
-                sv[u] = 0.0;
-                mv[u] = INFINITY;
-                if (act[u]) {
-                    const long long c = g[u] * 64 + lane;
-                    sv[u] = tree_load_sum(a.t, l - 1, c);
-                    mv[u] = tree_load_min(a.t, l - 1, c);
+                for (int k = 0; k < 16; ++k) mv[k] = cm[k];
+#pragma unroll 8
+                for (int k = 0; k < 32; ++k) {
+                    const f64x2 v = cs[k];
+                    s += v[0];
+                    s += v[1];
                 }
-            }
 #pragma unroll
-            for (int u = 0; u < TU; ++u) {
-                if (act[u]) {
-                    const double s = wave_sum_d(sv[u]);
-                    const float m = wave_min(mv[u]);
-                    if (lane == 0) {
-                        a.t.sum[l][g[u]] = s;
-                        a.t.mn[l][g[u]] = m;
-                    }
-                }
+                for (int k = 0; k < 16; ++k)
+                    m = fminf(fminf(m, fminf(mv[k][0], mv[k][1])), fminf(mv[k][2], mv[k][3]));
             }
+            a.t.sum[l][g] = s;
+            a.t.mn[l][g] = m;
         }
         __syncthreads();
     }
 }
-
