@@ -66,6 +66,7 @@ def parse_args():
     ap.add_argument("--baseline", action="store_true",
                     help="time the unfused eager-PyTorch update (reference op sequence) instead")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--tile-rows", default="auto", choices=["auto", "16", "32"])
     ap.add_argument("--dp-mode", default="both", choices=["both", "replicated", "grad_allreduce"],
                     help="data-parallel scheme for N > 1 (see the module docstring)")
     ap.add_argument("--dp-selftest", action="store_true",
@@ -121,7 +122,7 @@ def main() -> None:
                          dense_size=400, num_atoms=51, v_min=vrange[0], v_max=vrange[1],
                          device="cuda", replay_mem_size=args.replay_size,
                          replay_memory_prioritized=int(args.per), use_hip_graph=not args.no_graph,
-                         compute_dtype=args.dtype, num_steps_train=max(1, args.steps + args.warmup),
+                         compute_dtype=args.dtype, phase_tile_rows=args.tile_rows, num_steps_train=max(1, args.steps + args.warmup),
                          fused_learner="torch" if args.baseline else "auto", random_seed=2019)
     S, A = cfg["state_dim"], cfg["action_dim"]
     gamma_n = cfg["discount_rate"] ** cfg["n_step_returns"]

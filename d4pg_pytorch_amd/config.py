@@ -102,6 +102,7 @@ EXTENSION_DEFAULTS: Dict[str, Any] = {
     "ring_capacity": 4096,           # rows per explorer->replay shared-memory ring
     "ingest_chunk": 1024,            # rows per pinned H2D staging chunk
     "ingest_interval": 32,           # learner updates between two drains of the explorer rings
+    "phase_tile_rows": "auto",       # bf16 pipeline: batch rows per workgroup, "auto" | 16 | 32
     "sample_ahead": 8,               # uniform replay, bf16 pipeline: batches drawn per sampling launch (1: every update)
     # --- lifecycle ---
     "resume": None,                  # path to a learner checkpoint bundle to resume from

@@ -65,7 +65,8 @@ class HipCoreBf16(HipCore):
         # number of workgroups until they outnumber the 256 CUs, so 16-row tiles (more, smaller
         # workgroups) win up to B = 4096; beyond that 32-row tiles halve the weight traffic
         self.mt = 1
-        if B % 32 == 0 and B // 16 > 256:
+        want_rows = str(cfg.get("phase_tile_rows", "auto"))
+        if B % 32 == 0 and (want_rows == "32" or (want_rows == "auto" and B // 16 > 256)):
             need = max(H.lib().d4pg_phase_lds_bytes(self.dims, 2, 0), H.lib().d4pg_phase_lds_bytes(self.dims, 2, 1))
             if need <= LDS_LIMIT:
                 self.mt = 2
