@@ -21,7 +21,7 @@ Data-parallel modes (``--dp-mode``, N > 1):
   replicated      the sampled rows are all-gathered (one ~20 KB/rank collective, one update
                   ahead on a side stream) and every rank runs the update on the global
                   batch as ONE graph; no gradient traffic.  A learner update is latency
-                  bound, not throughput bound (81.6 us at batch 256, 92 us at 1024, 119 us at
+                  bound, not throughput bound (69 us at batch 256, 80 us at 1024, 91 us at
                   2048 on one MI355X), so replicating the arithmetic is cheaper than two
                   latency-bound gradient all-reduces on the critical path.
   grad_allreduce  every rank runs the update on its 256 rows and the critic and actor
@@ -29,6 +29,10 @@ Data-parallel modes (``--dp-mode``, N > 1):
   both (default)  times the two back to back; ``value`` is the replicated mode, the other
                   is reported as ``grad_allreduce_value``.
 Both make the update a single learner would make on the concatenated global batch.
+For N > 1 every rank also times the SAME configuration on its own GPU alone (no
+collectives, batch 256): ``single_gpu_same_config_value`` is what the N-GPU ``value`` should
+be divided by (and by N) for a like-for-like scaling efficiency, since the N == 1 default
+is the LunarLander shape.
 
 For N > 1 the driver launches this file under torch.distributed.run (one rank
 per GPU).  Rank 0 prints ONE JSON line.  ``value`` aggregates all ranks:
@@ -103,8 +107,11 @@ def main() -> None:
     from d4pg_pytorch_amd.config import default_config
     from d4pg_pytorch_amd.parallel.comm import LocalComm, TorchDistComm, attach_data_parallel
 
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one GPU per rank; ranks wrap around only when a multi-rank job is rehearsed on fewer GPUs
+    # (D4PG_DIST_BACKEND=gloo, see parallel/comm.py)
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world == 1 and args.dp_selftest:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
@@ -195,6 +202,15 @@ def main() -> None:
             assert drift == 0.0, f"learner replicas diverged (checksum difference {drift})"
             return core, t
 
+        if world > 1 or args.dp_selftest:
+            real_comm, comm = comm, LocalComm()          # this rank alone: no collectives
+            try:
+                _, dt_1 = run_grad_allreduce()
+                extra["single_gpu_same_config_value"] = round(args.steps / dt_1, 2)
+            except Exception as exc:
+                extra["single_gpu_same_config_error"] = repr(exc)[:200]
+            comm = real_comm
+            torch.cuda.empty_cache()
         if world == 1 and not args.dp_selftest:
             core, dt = run_grad_allreduce()
         elif args.dp_mode == "grad_allreduce":

@@ -80,7 +80,9 @@ class TorchDistComm(Comm):
         self.dist = dist
         self.device = torch.device(device) if device is not None else torch.device("cpu")
         if backend is None:
-            backend = "nccl" if self.device.type == "cuda" else "gloo"
+            # D4PG_DIST_BACKEND=gloo: rehearse a multi-rank job whose ranks share one GPU (RCCL refuses
+            # two ranks on a device); collectives on GPU tensors are then staged through the host
+            backend = os.environ.get("D4PG_DIST_BACKEND") or ("nccl" if self.device.type == "cuda" else "gloo")
         self.backend = backend
         self._owns = False
         if not dist.is_initialized():
@@ -99,15 +101,37 @@ class TorchDistComm(Comm):
         self.rank = dist.get_rank()
         self.world = dist.get_world_size()
 
+    def _staged(self, t: torch.Tensor) -> bool:
+        return self.backend != "nccl" and t.is_cuda
+
     def all_reduce_sum_(self, t):
+        if self._staged(t):
+            h = t.detach().cpu()                 # synchronises the current stream
+            self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM)
+            with torch.no_grad():
+                t.copy_(h)
+            return t
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return t
 
     def broadcast_(self, t, src=0):
+        if self._staged(t):
+            h = t.detach().cpu()
+            self.dist.broadcast(h, src=src)
+            with torch.no_grad():
+                t.copy_(h)
+            return t
         self.dist.broadcast(t, src=src)
         return t
 
     def all_gather_into_(self, out, inp):
+        if self._staged(inp):
+            h = inp.detach().reshape(-1).cpu()
+            parts = [torch.empty_like(h) for _ in range(self.world)]
+            self.dist.all_gather(parts, h)
+            with torch.no_grad():
+                out.view(-1).copy_(torch.cat(parts))
+            return out
         self.dist.all_gather_into_tensor(out.view(-1), inp.reshape(-1))
         return out
 
@@ -118,7 +142,7 @@ class TorchDistComm(Comm):
             self.dist.barrier()
 
     def all_reduce_max_scalar(self, v, device=None):
-        t = torch.tensor([float(v)], dtype=torch.float64, device=self.device)
+        t = torch.tensor([float(v)], dtype=torch.float64, device=self.device if self.backend == "nccl" else "cpu")
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 

@@ -99,6 +99,7 @@ v_min: -200.0
 v_max: 200.0
 device: cuda
 replay_device: hbm
+compute_dtype: bf16       # fused row-local pipeline (fp32 master weights); 'fp32' = exact f32 MFMA path
 use_hip_graph: true
 """,
     "bipedal_d4pg_per_8explorers.yml": """# BipedalWalker-shape D4PG with prioritised replay: the sum-tree lives in HBM, 8 CPU explorers feed it.
@@ -113,8 +114,9 @@ v_min: -100.0
 v_max: 300.0
 device: cuda
 replay_device: hbm
+compute_dtype: bf16       # fused row-local pipeline (fp32 master weights); 'fp32' = exact f32 MFMA path
 """,
-    "walker2d_d4pg_dp8.yml": """# Walker2d-shape D4PG, 8 data-parallel learners (one per MI355X), RCCL gradient all-reduce.
+    "walker2d_d4pg_dp8.yml": """# Walker2d-shape D4PG, 8 data-parallel learners (one per MI355X) over RCCL, replicated update on the all-gathered batch.
 env: Walker2d-v2
 model: d4pg
 num_agents: 3
@@ -124,6 +126,7 @@ v_min: 0.0
 v_max: 5000.0
 device: cuda
 replay_device: hbm
+compute_dtype: bf16       # fused row-local pipeline (fp32 master weights); 'fp32' = exact f32 MFMA path
 """,
     "half_cheetah_d4pg_dp8.yml": """# HalfCheetah-shape D4PG, 8 data-parallel learners.
 env: HalfCheetah-v2
@@ -136,6 +139,7 @@ v_min: 0.0
 v_max: 10000.0
 device: cuda
 replay_device: hbm
+compute_dtype: bf16       # fused row-local pipeline (fp32 master weights); 'fp32' = exact f32 MFMA path
 """,
     "ant_stress_d4pg.yml": """# Synthetic Ant-shape stress: obs 111, act 8, batch 4096, 10M-transition HBM replay per rank.
 env: Ant-v2
@@ -150,6 +154,7 @@ v_min: 0.0
 v_max: 4000.0
 device: cuda
 replay_device: hbm
+compute_dtype: bf16       # fused row-local pipeline (fp32 master weights); 'fp32' = exact f32 MFMA path
 envs_per_agent: 64
 """,
     "ant_stress_d3pg.yml": """# Same stress shape with the scalar (D3PG) critic path.
@@ -163,6 +168,7 @@ replay_mem_size: 10000000
 n_step_returns: 1
 device: cuda
 replay_device: hbm
+compute_dtype: bf16       # fused row-local pipeline (fp32 master weights); 'fp32' = exact f32 MFMA path
 envs_per_agent: 64
 """,
     "pendulum_d4pg_cpu.yml": """# Pendulum D4PG entirely on the CPU: learner + sampler + agent processes (plumbing, no GPU).
