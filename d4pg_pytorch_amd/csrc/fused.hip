@@ -326,12 +326,20 @@ __device__ __forceinline__ void put_lds4(__bf16* buf, int ld, int row0, int col,
 #pragma unroll
     for (int r = 0; r < 4; ++r) buf[(row0 + r) * ld + col] = (__bf16)v[r];
 }
-// 4 consecutive batch rows of one feature -> transposed global stash XT[col][b0 .. b0+3] (8-byte store)
-__device__ __forceinline__ void put_stash4(__bf16* XT, int ldt, int col, int b0, const f32x4& v) {
+// Activation / gradient stashes for the weight-gradient kernel: element (feature col, batch row b)
+// of a stash lives where the 32x32x16 MFMA of that kernel wants it, i.e. in operand-fragment
+// order [col / 32][b / 16][lane = 32 * ((b % 16) / 8) + col % 32][b % 8], so that one wave-wide
+// 16-byte load there is a contiguous 1 KB (a [feature][batch] matrix makes it 32 pieces of
+// 32 bytes in 32 rows).  Kb = batch rows rounded up to 32; features are padded to 32.
+__device__ __forceinline__ size_t stash_off(int col, int b, int Kb) {
+    return ((size_t)(col >> 5) * (Kb >> 4) + (b >> 4)) * 512 + ((((b >> 3) & 1) << 5) + (col & 31)) * 8 + (b & 7);
+}
+// 4 consecutive batch rows (b0 % 4 == 0) of one feature: 8 contiguous bytes of the stash
+__device__ __forceinline__ void put_stash4(__bf16* XT, int Kb, int col, int b0, const f32x4& v) {
     bf16x4 o;
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[r] = (__bf16)v[r];
-    *reinterpret_cast<bf16x4*>(XT + (size_t)col * ldt + b0) = o;
+    *reinterpret_cast<bf16x4*>(XT + stash_off(col, b0, Kb)) = o;
 }
 
 // Batch rows read straight out of the gathered chunk buffers of csrc/replay.hip (packed rows
@@ -374,7 +382,7 @@ __device__ __forceinline__ const float* row_of(const RowSrc& r, int b) {
 
 struct PhaseDims {
     int B;            // batch rows (multiple of 16*MT)
-    int Bp;           // leading dimension of the transposed stashes (multiple of 32, >= B)
+    int Bp;           // batch rows rounded up to a multiple of 32 (K of the weight-gradient GEMMs, stash_off)
     int S, A, H, NO;  // state, action, hidden, critic outputs (atoms or 1)
     int ldx_in;       // leading dimension of the fp32 input matrices (floats)
     int ldx;          // LDS leading dim of the input tile   = pad32(S + A) + LDS_PAD
@@ -463,7 +471,7 @@ __device__ __forceinline__ void load_input(const RowSrc& src, int row0, int M, i
         float v = 0.f;
         if (c < ncols) {
             v = row_of(src, row0 + r)[c];
-            if (stashT != nullptr) stashT[(size_t)c * ldt + row0 + r] = (__bf16)v;
+            if (stashT != nullptr) stashT[stash_off(c, row0 + r, ldt)] = (__bf16)v;
         }
         dst[r * ld_dst + c] = (__bf16)v;
     }
@@ -498,7 +506,7 @@ __device__ __forceinline__ void critic_rows(const CriticPhaseArgs& a, int row0, 
                 if (j < d.NO) {
                     const __bf16 v = (__bf16)(dl[s] * scale);
                     dlg[r * d.ldd + j] = v;
-                    a.dlT[(size_t)j * d.Bp + b] = v;
+                    a.dlT[stash_off(j, b, d.Bp)] = v;
                 }
             }
             if (lane == 0) {
@@ -514,7 +522,7 @@ __device__ __forceinline__ void critic_rows(const CriticPhaseArgs& a, int row0, 
             const float l = diff * diff;
             const __bf16 v = (__bf16)(2.f * diff * scale);
             dlg[r * d.ldd] = v;
-            a.dlT[b] = v;
+            a.dlT[stash_off(0, b, d.Bp)] = v;
             a.per_loss[b] = l;
             a.priority[b] = fabsf(l) + 1e-4f;
         }
@@ -1022,12 +1030,12 @@ D4PG_API int d4pg_phase_lds_bytes(const PhaseDims* d, int mt, int actor) {
 // v_mfma_f32_32x32x16_bf16, four waves split the batch (K) and combine through LDS.
 // ---------------------------------------------------------------------------------------
 struct WgradDesc {
-    const __bf16* AT;   // dY^T [rowsA][Bp]
-    const __bf16* BT;   // X^T  [rowsB][Bp]
+    const __bf16* AT;   // dY stash, rowsA features x Bp batch rows in stash_off order
+    const __bf16* BT;   // X stash,  rowsB features x Bp batch rows
     float* C;           // dW fp32 [M][ldc]
     float* rowsum;      // db fp32 [M] or null
     int M, N;           // true output rows / columns
-    int rowsA, rowsB;   // allocated (padded) rows of the stashes: loads are clamped to them
+    int rowsA, rowsB;   // allocated features of the stashes (multiples of 32)
     int ldc;
     int tiles_m, tiles_n, tile_base;
     // ---- fused optimiser (single-GPU path): where this matrix lives in the flat buffers ----
@@ -1062,7 +1070,7 @@ struct WgradAdam {
 struct WgradGroup {
     WgradDesc p[WG_MAX];
     int count, total_tiles;
-    int Bp;             // K (multiple of 32)
+    int Bp;             // K: batch rows rounded up to a multiple of 32
     int pad_;
     WgradAdam opt;
 };
@@ -1104,9 +1112,15 @@ __device__ __forceinline__ float adam_elem(const WgradAdam& o, long long idx, fl
     return p;
 }
 
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradGroup g) {
-    __shared__ float red[4 * 16 * 64];
-    __shared__ float cs[4 * 32];
+// NWV waves split the batch (K); waves 0..3 then finish the tile (sum of the NWV partial
+// tiles, optimiser, shadows).  More waves = more stash loads in flight per CU: the loop is
+// bound by the latency of those loads (the stashes were just written by other CUs), so NWV
+// grows with the batch.
+template <int NWV>
+__global__ __launch_bounds__(64 * NWV) void wgrad_kernel(const WgradGroup g) {
+    extern __shared__ __attribute__((aligned(16))) float wg_smem[];
+    float* red = wg_smem;                      // [NWV][16 accumulator registers][64 lanes]
+    float* cs = wg_smem + NWV * 16 * 64;       // [NWV][32] partial row sums
     const int total = g.total_tiles;
     const int id = blockIdx.x;
     const int xcd = id & 7, local = id >> 3;
@@ -1125,24 +1139,24 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGroup g) {
     const int r = lane & 31, h = lane >> 5;
     const int m = tm * 32 + r, n = tn * 32 + r;
     const bool m_ok = m < d.M, n_ok = n < d.N;
-    const int m_c = m < d.rowsA ? m : d.rowsA - 1, n_c = n < d.rowsB ? n : d.rowsB - 1;
-    const __bf16* arow = d.AT + (size_t)m_c * g.Bp + 8 * h;
-    const __bf16* brow = d.BT + (size_t)n_c * g.Bp + 8 * h;
+    // operand fragments of (tile, k-step) are contiguous 1 KB blocks of the stashes (stash_off)
+    const int ksteps = g.Bp >> 4;              // k-steps of 16
+    const __bf16* arow = d.AT + ((size_t)tm * ksteps * 64 + lane) * 8;
+    const __bf16* brow = d.BT + ((size_t)tn * ksteps * 64 + lane) * 8;
     // fused optimiser: this thread finishes rows pm0 .. pm0+3 of column pn of the tile
     const WgradAdam& o = g.opt;
     const bool fuse = o.p != nullptr;
     const int pm0 = tm * 32 + 8 * wave + 4 * h, pn = tn * 32 + r;
     AdamState ast[4];
     float step_size = 0.f, inv_sqrt_bc2 = 0.f;
-    if (fuse) {
+    if (fuse && wave < 4) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (pm0 + i < d.M && pn < d.N) ast[i] = adam_fetch(o, d.w_off + (long long)(pm0 + i) * d.ldc + pn);
         step_size = o.st->bc1;
         inv_sqrt_bc2 = o.st->bc2;
     }
-    const int ksteps = g.Bp >> 4;              // k-steps of 16
-    const int per = (ksteps + 3) >> 2;
+    const int per = (ksteps + NWV - 1) / NWV;
     const int k0 = wave * per, k1 = min(ksteps, k0 + per);
     f32x16 acc;
 #pragma unroll
@@ -1153,8 +1167,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGroup g) {
     const bool want_rowsum = d.rowsum != nullptr && tn == 0;
 #pragma unroll 8
     for (int ks = k0; ks < k1; ++ks) {
-        bf16x8 av = *reinterpret_cast<const bf16x8*>(arow + ks * 16);
-        bf16x8 bv = *reinterpret_cast<const bf16x8*>(brow + ks * 16);
+        bf16x8 av = *reinterpret_cast<const bf16x8*>(arow + ks * 512);
+        bf16x8 bv = *reinterpret_cast<const bf16x8*>(brow + ks * 512);
         av = m_ok ? av : zero;
         bv = n_ok ? bv : zero;
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
@@ -1170,58 +1184,63 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGroup g) {
         if (lane < 32) cs[wave * 32 + lane] = asum;
     }
     __syncthreads();
-    if (fuse) {
-        step_size = o.lr / step_size;
-        inv_sqrt_bc2 = 1.f / sqrtf(inv_sqrt_bc2);
-    }
-    const int wv = threadIdx.x >> 6;
-    const int cn = tn * 32 + r;
-    const int cm0 = tm * 32 + 8 * wv + 4 * h;      // this thread finishes rows cm0 .. cm0+3 of column cn
-    f32x4 pnew = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int reg = 4 * wv + i;
-        const float gv = red[(0 * 16 + reg) * 64 + lane] + red[(1 * 16 + reg) * 64 + lane] +
-                         red[(2 * 16 + reg) * 64 + lane] + red[(3 * 16 + reg) * 64 + lane];
-        const int cm = cm0 + i;
-        if (cm < d.M && cn < d.N) {
-            d.C[(size_t)cm * d.ldc + cn] = gv;
-            if (fuse) {
-                float tv;
-                const float pv = adam_apply(o, d.w_off + (long long)cm * d.ldc + cn, ast[i], gv, step_size,
-                                            inv_sqrt_bc2, tv);
-                pnew[i] = pv;
-                if (d.sf_off >= 0) {
-                    const long long so = d.sf_off + packed_off(cm, cn, d.sf_ld >> 5);
-                    o.p_shadow[so] = (__bf16)pv;
-                    o.t_shadow[so] = (__bf16)tv;
+    if (wave < 4) {
+        if (fuse) {
+            step_size = o.lr / step_size;
+            inv_sqrt_bc2 = 1.f / sqrtf(inv_sqrt_bc2);
+        }
+        const int wv = threadIdx.x >> 6;
+        const int cn = tn * 32 + r;
+        const int cm0 = tm * 32 + 8 * wv + 4 * h;      // this thread finishes rows cm0 .. cm0+3 of column cn
+        f32x4 pnew = {0.f, 0.f, 0.f, 0.f};
+    #pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int reg = 4 * wv + i;
+            float gv = 0.f;
+    #pragma unroll
+            for (int w = 0; w < NWV; ++w) gv += red[(w * 16 + reg) * 64 + lane];
+            const int cm = cm0 + i;
+            if (cm < d.M && cn < d.N) {
+                d.C[(size_t)cm * d.ldc + cn] = gv;
+                if (fuse) {
+                    float tv;
+                    const float pv = adam_apply(o, d.w_off + (long long)cm * d.ldc + cn, ast[i], gv, step_size,
+                                                inv_sqrt_bc2, tv);
+                    pnew[i] = pv;
+                    if (d.sf_off >= 0) {
+                        const long long so = d.sf_off + packed_off(cm, cn, d.sf_ld >> 5);
+                        o.p_shadow[so] = (__bf16)pv;
+                        o.t_shadow[so] = (__bf16)tv;
+                    }
                 }
             }
         }
-    }
-    if (fuse && d.sb_off >= 0 && cn >= d.sb_c0 && cn < d.sb_c1 && cn < d.N) {
-        // transposed shadow: 4 consecutive output rows (cm0 % 4 == 0) of one input column are 4
-        // consecutive k of one packed row -> one 8-byte store
-        __bf16* dst = o.p_shadow + d.sb_off + packed_off(cn - d.sb_c0, cm0, d.sb_ld >> 5);
-        if (cm0 + 3 < d.M) {
-            bf16x4 pk;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) pk[i] = (__bf16)pnew[i];
-            *reinterpret_cast<bf16x4*>(dst) = pk;
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (cm0 + i < d.M) dst[i] = (__bf16)pnew[i];
+        if (fuse && d.sb_off >= 0 && cn >= d.sb_c0 && cn < d.sb_c1 && cn < d.N) {
+            // transposed shadow: 4 consecutive output rows (cm0 % 4 == 0) of one input column are 4
+            // consecutive k of one packed row -> one 8-byte store
+            __bf16* dst = o.p_shadow + d.sb_off + packed_off(cn - d.sb_c0, cm0, d.sb_ld >> 5);
+            if (cm0 + 3 < d.M) {
+                bf16x4 pk;
+    #pragma unroll
+                for (int i = 0; i < 4; ++i) pk[i] = (__bf16)pnew[i];
+                *reinterpret_cast<bf16x4*>(dst) = pk;
+            } else {
+    #pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (cm0 + i < d.M) dst[i] = (__bf16)pnew[i];
+            }
         }
-    }
-    if (d.rowsum != nullptr && tn == 0 && threadIdx.x < 32) {
-        const int cm = tm * 32 + threadIdx.x;
-        if (cm < d.M) {
-            const float gb = cs[threadIdx.x] + cs[32 + threadIdx.x] + cs[64 + threadIdx.x] + cs[96 + threadIdx.x];
-            d.rowsum[cm] = gb;
-            if (fuse) {
-                float tv;
-                adam_elem(o, d.b_off + cm, gb, step_size, inv_sqrt_bc2, tv);
+        if (d.rowsum != nullptr && tn == 0 && threadIdx.x < 32) {
+            const int cm = tm * 32 + threadIdx.x;
+            if (cm < d.M) {
+                float gb = 0.f;
+    #pragma unroll
+                for (int w = 0; w < NWV; ++w) gb += cs[w * 32 + threadIdx.x];
+                d.rowsum[cm] = gb;
+                if (fuse) {
+                    float tv;
+                    adam_elem(o, d.b_off + cm, gb, step_size, inv_sqrt_bc2, tv);
+                }
             }
         }
     }
@@ -1237,14 +1256,19 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGroup g) {
         vl = wave_sum(vl);
         pl = wave_sum(pl);
         if (lane == 0) {
-            cs[wv] = vl;
-            cs[4 + wv] = pl;
+            cs[wave] = vl;
+            cs[NWV + wave] = pl;
         }
         __syncthreads();
         if (threadIdx.x == 0) {
             if (o.metrics != nullptr) {
-                o.metrics[MET_VALUE_LOSS] += (cs[0] + cs[1] + cs[2] + cs[3]) * o.inv_B;
-                o.metrics[MET_POLICY_LOSS] += (cs[4] + cs[5] + cs[6] + cs[7]) * o.inv_B;
+                float svl = 0.f, spl = 0.f;
+                for (int w = 0; w < NWV; ++w) {
+                    svl += cs[w];
+                    spl += cs[NWV + w];
+                }
+                o.metrics[MET_VALUE_LOSS] += svl * o.inv_B;
+                o.metrics[MET_POLICY_LOSS] += spl * o.inv_B;
                 o.metrics[MET_COUNT] += 1.f;
             }
             o.st->step_done = o.st->step_cur;
@@ -1252,12 +1276,25 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGroup g) {
     }
 }
 
+template <typename K>
+static int launch_wgrad(K kernel, int nwv, int grid, const WgradGroup& g, hipStream_t stream) {
+    const int lds = nwv * (16 * 64 + 32) * 4;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * nwv), lds, stream, g);
+    return (int)hipGetLastError();
+}
+
 D4PG_API int d4pg_wgrad(WgradGroup* g, hipStream_t stream) {
     if (g->count < 1 || g->count > WG_MAX || g->Bp < 32 || (g->Bp & 31)) return -1;
     int base = 0;
     for (int i = 0; i < g->count; ++i) {
         WgradDesc& d = g->p[i];
-        if (d.M < 1 || d.N < 1 || d.rowsA < 1 || d.rowsB < 1 || d.ldc < d.N) return -2;
+        if (d.M < 1 || d.N < 1 || d.ldc < d.N) return -2;
+        // the stashes hold whole 32-feature blocks (stash_off): every tile row must exist
+        if ((d.rowsA & 31) || (d.rowsB & 31) || d.rowsA < d.M || d.rowsB < d.N) return -2;
         if (d.AT == nullptr || d.BT == nullptr || d.C == nullptr) return -3;
         if ((((uintptr_t)d.AT) | ((uintptr_t)d.BT)) & 15) return -4;
         d.tiles_m = (d.M + 31) / 32;
@@ -1266,6 +1303,12 @@ D4PG_API int d4pg_wgrad(WgradGroup* g, hipStream_t stream) {
         base += d.tiles_m * d.tiles_n;
     }
     g->total_tiles = base;
-    hipLaunchKernelGGL(wgrad_kernel, dim3(base), dim3(256), 0, stream, *g);
-    return (int)hipGetLastError();
+    // waves per workgroup (they split the batch): one k-step of 16 batch rows per wave up to 16 waves;
+    // measured on MI355X (us per update, batch 256 / 1024 / 2048): 4 waves 68.0 / 79.2 / 91.8,
+    // 8 waves 66.5 / 73.5 / 79.3, 16 waves 66.2 / 70.8 / 74.8.  D4PG_WGRAD_WAVES overrides (tuning).
+    int nwv = g->Bp >= 256 ? 16 : (g->Bp >= 128 ? 8 : 4);
+    if (const char* e = getenv("D4PG_WGRAD_WAVES")) nwv = atoi(e);
+    if (nwv == 16) return launch_wgrad(wgrad_kernel<16>, 16, base, *g, stream);
+    if (nwv == 8) return launch_wgrad(wgrad_kernel<8>, 8, base, *g, stream);
+    return launch_wgrad(wgrad_kernel<4>, 4, base, *g, stream);
 }

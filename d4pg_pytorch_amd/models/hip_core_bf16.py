@@ -21,6 +21,8 @@ layout and checkpoints are those of :class:`HipCore`.
 """
 from __future__ import annotations
 
+import os
+
 from typing import Callable, Dict, List, Optional
 
 import torch
@@ -43,11 +45,11 @@ class HipCoreBf16(HipCore):
         self.sl = ShadowLayout.build(lay)
         self.shadow_online = torch.zeros(self.sl.numel, dtype=torch.bfloat16, device=dev)
         self.shadow_target = torch.zeros(self.sl.numel, dtype=torch.bfloat16, device=dev)
-        self.Bp = pad32(B)
+        self.Bp = pad32(B)              # K of the weight-gradient GEMMs
         self.zero_bias = torch.zeros(pad16(max(Hd, S + A, NO)), dtype=torch.float32, device=dev)   # bias of the dX layers
 
         def stash(rows):
-            return torch.zeros(pad16(rows), self.Bp, dtype=torch.bfloat16, device=dev)
+            return torch.zeros(pad32(rows), self.Bp, dtype=torch.bfloat16, device=dev)   # fragment order, see stash_off
         # critic phase stashes
         self.saT, self.c_h1T, self.c_h2T = stash(S + A), stash(Hd), stash(Hd)
         self.c_dlT, self.c_dh2T, self.c_dh1T = stash(NO), stash(Hd), stash(Hd)

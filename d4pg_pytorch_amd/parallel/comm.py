@@ -20,7 +20,9 @@ ROCm, ``gloo`` on CPU).  :class:`LocalComm` is the world-size-1 no-op.
 """
 from __future__ import annotations
 
+import contextlib
 import os
+import sys
 from typing import Optional
 
 import torch
@@ -69,6 +71,22 @@ class LocalComm(Comm):
         return float(v)
 
 
+@contextlib.contextmanager
+def _stdout_to_stderr():
+    """File-descriptor level redirect: RCCL prints a version banner to stdout when it creates its
+    first communicator, which would corrupt the output of programs that print machine-readable
+    results there."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 class TorchDistComm(Comm):
     """``torch.distributed`` process group: RCCL over xGMI on GPUs, gloo on CPU."""
 
@@ -95,8 +113,14 @@ class TorchDistComm(Comm):
                 init_method = "env://"
             if backend == "nccl":
                 kwargs["device_id"] = self.device
-            dist.init_process_group(backend=backend, init_method=init_method,
-                                    timeout=datetime.timedelta(seconds=timeout_s), **kwargs)
+            with _stdout_to_stderr():
+                dist.init_process_group(backend=backend, init_method=init_method,
+                                        timeout=datetime.timedelta(seconds=timeout_s), **kwargs)
+                # create the communicator now (it is otherwise created by the first collective)
+                warm = torch.zeros(1, device=self.device if backend == "nccl" else "cpu")
+                dist.all_reduce(warm)
+                if warm.is_cuda:
+                    torch.cuda.synchronize(self.device)
             self._owns = True
         self.rank = dist.get_rank()
         self.world = dist.get_world_size()
