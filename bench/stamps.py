@@ -38,7 +38,11 @@ def main():
     acc = None
     n = 0
     for it in range(60):
-        core.update_from_replay()
+        # steady state: a burst of back-to-back updates, the stamps are those of the last one (a launch
+        # after an idle gap runs at a lower clock with cold instruction / scalar caches and reads 2x)
+        done = 0
+        while done < 64:
+            done += core.update_from_replay_many(64 - done)
         torch.cuda.synchronize()
         buf = (C.c_ulonglong * 64)()
         assert fn(buf) == 0

@@ -46,7 +46,15 @@ D4PG_API int d4pg_read_stamps(unsigned long long* out) {
 #define STAMP_SYNC()
 #endif
 
-constexpr int NW = 8;          // waves per workgroup (2 per SIMD: twice the weight bytes in flight)
+// Waves per workgroup of the phase kernels.  Every wave keeps one weight tile (13 KB at H = 400) in
+// flight, and a layer is bound by the latency of those loads: measured per update at batch 256,
+// 8 waves 66.2 us, 12 waves 63.6 us, 16 waves 64.2 us (16 waves = 4 per SIMD leave 128 registers per
+// wave, which the two prefetch slots of the layer chain overflow; 12 = 3 per SIMD leave 168).
+// The kernels are instantiated for 12 and for 8 waves; the host picks 8 once the grid has more
+// workgroups than the chip has CUs (batch 4096: 12 waves 107.8 us, 8 waves 93.5 us per update; capping
+// the 8-wave variant at 128 registers so that two workgroups fit on a CU costs 14 spills: 97.8 us).
+constexpr int NW_FEW = 12;     // grid <= 256 workgroups
+constexpr int NW_MANY = 8;
 constexpr int LDS_PAD = 8;     // bf16 elements appended to every LDS row (16 B: breaks the bank stride)
 
 struct LayerW {
@@ -128,7 +136,7 @@ __device__ __forceinline__ void ct_epilogue(const f32x4 (&acc)[MT], float bias, 
     }
 }
 
-template <int MT, int KS, typename F, typename P>
+template <int NW, int MT, int KS, typename F, typename P>
 __device__ __forceinline__ void layer_ct(TileB<KS>& t, const __bf16* A, int lda, const LayerW& L, F&& epi, P&& pre) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -164,7 +172,7 @@ __device__ __forceinline__ void layer_ct(TileB<KS>& t, const __bf16* A, int lda,
 // Generic layer (any K-steps, any tile count): no register staging beyond one k-step,
 // no prefetch.  Used for hidden sizes without a compile-time variant and for narrow-K
 // layers that exceed the register block of layer_rt.
-template <int MT, typename F>
+template <int NW, int MT, typename F>
 __device__ __forceinline__ void layer_gen(const __bf16* A, int lda, const LayerW& L, int first_tile, F&& epi) {
     const int lane = threadIdx.x & 63;
     const int c = lane & 15, kg = lane >> 4;
@@ -198,16 +206,18 @@ __device__ __forceinline__ void layer_gen(const __bf16* A, int lda, const LayerW
 // Narrow-K layers (inputs, logits, actions: K <= 128): the wave's whole share of the
 // layer (up to RT_T tiles x RT_K k-steps) is loaded in one burst, normally by the previous
 // layer's `pre`, so the layer itself starts on its MFMAs.
-constexpr int RT_T = 4;
-template <int RT_K>
+constexpr int rt_tiles(int nw) { return (32 + nw - 1) / nw; }   // tiles per wave held in registers: covers >= 512 output columns
+template <int NW, int RT_K>
 struct RtB {
+    static constexpr int RT_T = rt_tiles(NW);
     bf16x8 b[RT_T][RT_K];
     float bias[RT_T];
 };
 
-template <int RT_K>
-__device__ __forceinline__ RtB<RT_K> fetch_rt(const LayerW& L, int wave, int lane) {
-    RtB<RT_K> r;                  // fresh value, see fetch_tile
+template <int NW, int RT_K>
+__device__ __forceinline__ RtB<NW, RT_K> fetch_rt(const LayerW& L, int wave, int lane) {
+    constexpr int RT_T = rt_tiles(NW);
+    RtB<NW, RT_K> r;              // fresh value, see fetch_tile
     if (L.ks > RT_K) return r;    // layer_rt falls back to layer_gen
 #pragma unroll
     for (int t = 0; t < RT_T; ++t) {
@@ -223,14 +233,15 @@ __device__ __forceinline__ RtB<RT_K> fetch_rt(const LayerW& L, int wave, int lan
     return r;
 }
 
-template <int MT, int RT_K, typename F, typename P>
-__device__ __forceinline__ void layer_rt(const RtB<RT_K>& r, const __bf16* A, int lda, const LayerW& L, F&& epi, P&& pre) {
+template <int NW, int MT, int RT_K, typename F, typename P>
+__device__ __forceinline__ void layer_rt(const RtB<NW, RT_K>& r, const __bf16* A, int lda, const LayerW& L, F&& epi, P&& pre) {
+    constexpr int RT_T = rt_tiles(NW);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 15, kg = lane >> 4;
     if (L.ks > RT_K) {
         pre();
-        layer_gen<MT>(A, lda, L, wave, epi);
+        layer_gen<NW, MT>(A, lda, L, wave, epi);
         return;
     }
     // all MFMAs of the wave's register block first: the wait for `r` must come BEFORE the
@@ -273,17 +284,17 @@ __device__ __forceinline__ void layer_rt(const RtB<RT_K>& r, const __bf16* A, in
         }
     }
     // more than RT_T tiles per wave (hidden sizes above 16 * RT_T * NW): stream the rest
-    layer_gen<MT>(A, lda, L, wave + RT_T * NW, epi);
+    layer_gen<NW, MT>(A, lda, L, wave + RT_T * NW, epi);
 }
 
 // Per-kernel prefetch state + dispatch.  Two register sets (slots) alternate along the chain
 // of hidden-K layers: the layer running out of slot X prefetches its successor into slot
 // 1 - X (or into the narrow-K block).  Hidden-K layers run layer_ct when the kernel was
 // instantiated for that K (KSH > 0), else the generic path.
-template <int MT, int KSH, int KSN>
+template <int NW, int MT, int KSH, int KSN>
 struct Chain {
     TileB<(KSH > 0 ? KSH : 1)> t0, t1;   // first tile of the next hidden-K layer (slot 0 / 1)
-    RtB<KSN> nr;                         // the next narrow-K layer (up to KSN K-steps)
+    RtB<NW, KSN> nr;                     // the next narrow-K layer (up to KSN K-steps)
     int wave, lane;
     __device__ __forceinline__ Chain() {
         lane = threadIdx.x & 63;
@@ -298,22 +309,22 @@ struct Chain {
                 t1 = fetch_tile<KSH>(L, wave, lane);
         }
     }
-    __device__ __forceinline__ void prefetch_n(const LayerW& L) { nr = fetch_rt<KSN>(L, wave, lane); }
+    __device__ __forceinline__ void prefetch_n(const LayerW& L) { nr = fetch_rt<NW, KSN>(L, wave, lane); }
     template <int SLOT, typename F, typename P>
     __device__ __forceinline__ void hidden(const __bf16* A, int lda, const LayerW& L, F&& epi, P&& pre) {
         if constexpr (KSH > 0) {
             if constexpr (SLOT == 0)
-                layer_ct<MT, KSH>(t0, A, lda, L, epi, pre);
+                layer_ct<NW, MT, KSH>(t0, A, lda, L, epi, pre);
             else
-                layer_ct<MT, KSH>(t1, A, lda, L, epi, pre);
+                layer_ct<NW, MT, KSH>(t1, A, lda, L, epi, pre);
         } else {
             pre();
-            layer_gen<MT>(A, lda, L, wave, epi);
+            layer_gen<NW, MT>(A, lda, L, wave, epi);
         }
     }
     template <typename F, typename P>
     __device__ __forceinline__ void narrow(const __bf16* A, int lda, const LayerW& L, F&& epi, P&& pre) {
-        layer_rt<MT, KSN>(nr, A, lda, L, epi, pre);
+        layer_rt<NW, MT, KSN>(nr, A, lda, L, epi, pre);
     }
 };
 
@@ -477,8 +488,27 @@ __device__ __forceinline__ void load_input(const RowSrc& src, int row0, int M, i
     }
 }
 
+// L2 warmer role.  The bf16 weights change every update, so the first touch of every weight line
+// by an XCD misses its L2 and is served by the Infinity Cache at ~2.5x the latency; a phase is a chain
+// of loads whose latency is what it costs.  Extra workgroups (slice `slice` of `nslices` on each XCD;
+// consecutive workgroup ids go round the 8 XCDs) stream the layers in the order the phase uses them,
+// a few microseconds ahead of the workgroups that compute, which then hit in L2.
+// (One call per layer, layers passed by reference: an array of layer pointers indexed in a loop
+// would force the kernel arguments out of scalar registers into memory for the whole kernel.)
+__device__ __forceinline__ void warm_layer(const LayerW& L, int slice, int nslices, unsigned& acc) {
+    const int chunks = L.ntiles * L.ks * 64;                 // 16-byte chunks of the packed shadow
+    const int per = (chunks + nslices - 1) / nslices;
+    const int lo = slice * per, hi = min(chunks, lo + per);
+    const u32x4* p = reinterpret_cast<const u32x4*>(L.W);
+#pragma unroll 4
+    for (int i = lo + (int)threadIdx.x; i < hi; i += blockDim.x) {
+        const u32x4 v = p[i];
+        acc ^= v[0] ^ v[1] ^ v[2] ^ v[3];
+    }
+}
+
 // Loss of the rows of one tile, one wave per row (SL atom slots per lane: 1 for <= 64 atoms).
-template <int SL, int M>
+template <int NW, int SL, int M>
 __device__ __forceinline__ void critic_rows(const CriticPhaseArgs& a, int row0, int lane, int wave, const float* lg_t,
                                             const float* lg_o, __bf16* dlg, float* sp, float* sb, const float* rs) {
     const PhaseDims& d = a.d;
@@ -529,12 +559,12 @@ __device__ __forceinline__ void critic_rows(const CriticPhaseArgs& a, int row0, 
     }
 }
 
-template <int MT, int KSH, int KSN>
+template <int NW, int MT, int KSH, int KSN>
 __device__ __forceinline__ void actor_forward_role(const CriticPhaseArgs& a, int row0, char* smem) {
     constexpr int M = 16 * MT;
     const PhaseDims& d = a.d;
     const ActorFwd& f = a.fwd;
-    Chain<MT, KSH, KSN> ch;
+    Chain<NW, MT, KSH, KSN> ch;
     ch.prefetch_n(f.af[0]);
     int off = 0;
     auto carve = [&](int bytes) { char* p = smem + off; off += (bytes + 15) & ~15; return p; };
@@ -580,7 +610,7 @@ __device__ __forceinline__ void actor_forward_role(const CriticPhaseArgs& a, int
     copy16(f.g_pi + (size_t)row0 * ldpi, pi, M * ldpi * 4);
 }
 
-template <int MT, int KSH, int KSN>
+template <int NW, int MT, int KSH, int KSN>
 __global__ __launch_bounds__(64 * NW) void critic_phase_kernel(const CriticPhaseArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int M = 16 * MT;
@@ -588,12 +618,38 @@ __global__ __launch_bounds__(64 * NW) void critic_phase_kernel(const CriticPhase
     const int row0 = blockIdx.x * M;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (row0 >= 2 * d.B) {     // beyond both halves: L2 warmers
+        const int sl = (blockIdx.x - 2 * (d.B / M)) >> 3, nsl = (gridDim.x - 2 * (d.B / M) + 7) >> 3;
+        unsigned acc = 0;
+        warm_layer(a.ta[0], sl, nsl, acc);
+        warm_layer(a.fwd.af[0], sl, nsl, acc);
+        warm_layer(a.ta[1], sl, nsl, acc);
+        warm_layer(a.fwd.af[1], sl, nsl, acc);
+        warm_layer(a.ta[2], sl, nsl, acc);
+        warm_layer(a.fwd.af[2], sl, nsl, acc);
+        warm_layer(a.tc[0], sl, nsl, acc);
+        warm_layer(a.tc[1], sl, nsl, acc);
+        warm_layer(a.tc[2], sl, nsl, acc);
+        warm_layer(a.cf[0], sl, nsl, acc);
+        warm_layer(a.cf[1], sl, nsl, acc);
+        warm_layer(a.cf[2], sl, nsl, acc);
+        warm_layer(a.cb3, sl, nsl, acc);
+        warm_layer(a.cb2, sl, nsl, acc);
+        asm volatile("" ::"v"(acc));      // the loads must be issued and returned; their values are not used
+        return;
+    }
     if (row0 >= d.B) {         // the second half of the grid: actor forward
-        actor_forward_role<MT, KSH, KSN>(a, row0 - d.B, smem);
+        // The per-update tick (step counter, Adam bias corrections: two double-precision pow() on one
+        // thread, microseconds) runs in a workgroup that finishes long before the critic role does.
+        // It reads step_done (like packed_src) and writes step_cur / bc1 / bc2 / per_beta, which
+        // nothing in this launch reads.
+        if (a.pk.enabled && a.pk.do_tick && row0 == d.B && threadIdx.x == 0)
+            devstate_tick(a.pk.st, a.pk.beta1, a.pk.beta2, a.pk.per_b0, a.pk.per_b1, a.pk.total_steps);
+        actor_forward_role<NW, MT, KSH, KSN>(a, row0 - d.B, smem);
         return;
     }
     STAMP(0, 31);
-    Chain<MT, KSH, KSN> ch;
+    Chain<NW, MT, KSH, KSN> ch;
     ch.prefetch_n(a.ta[0]);
     // ---- carve LDS (every offset a multiple of 16 bytes) ----
     int off = 0;
@@ -630,10 +686,6 @@ __global__ __launch_bounds__(64 * NW) void critic_phase_kernel(const CriticPhase
             rs_w = (a.weights ? a.weights[b] : 1.f) * d.inv_B;
         }
     }
-    // the per-update tick reads step_done (like packed_src above) and writes step_cur / bc1 / bc2 /
-    // per_beta, which nothing in this kernel reads
-    if (a.pk.enabled && a.pk.do_tick && blockIdx.x == 0 && threadIdx.x == 0)
-        devstate_tick(a.pk.st, a.pk.beta1, a.pk.beta2, a.pk.per_b0, a.pk.per_b1, a.pk.total_steps);
     // K-padding columns are never written by an epilogue: clear them once (the matching
     // weight columns are zero, but LDS garbage could be NaN)
     zero_block(dlg, M * d.ldd * 2);
@@ -716,9 +768,9 @@ __global__ __launch_bounds__(64 * NW) void critic_phase_kernel(const CriticPhase
     STAMP(0, 9);
     // ---- loss: one wave per row ----
     if (d.distributional && d.NO <= 64)
-        critic_rows<1, M>(a, row0, lane, wave, lg_t, lg_o, dlg, sp, sb, rs);
+        critic_rows<NW, 1, M>(a, row0, lane, wave, lg_t, lg_o, dlg, sp, sb, rs);
     else
-        critic_rows<4, M>(a, row0, lane, wave, lg_t, lg_o, dlg, sp, sb, rs);
+        critic_rows<NW, 4, M>(a, row0, lane, wave, lg_t, lg_o, dlg, sp, sb, rs);
     __syncthreads();
     STAMP(0, 10);
     // ---- backward through critic layers 3 and 2 (activation gradients only) ----
@@ -761,7 +813,7 @@ struct ActorPhaseArgs {
     TreeUpdateArgs tree;   // tree.n == 0: none
 };
 
-template <int SL, int M>
+template <int NW, int SL, int M>
 __device__ __forceinline__ void actor_rows(const ActorPhaseArgs& a, int row0, int lane, int wave, const float* lg_o,
                                            __bf16* dlg) {
     const PhaseDims& d = a.d;
@@ -788,7 +840,7 @@ __device__ __forceinline__ void actor_rows(const ActorPhaseArgs& a, int row0, in
     }
 }
 
-template <int MT, int KSH, int KSN>
+template <int NW, int MT, int KSH, int KSN>
 __global__ __launch_bounds__(64 * NW) void actor_phase_kernel(const ActorPhaseArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int M = 16 * MT;
@@ -796,12 +848,27 @@ __global__ __launch_bounds__(64 * NW) void actor_phase_kernel(const ActorPhaseAr
     const int row0 = blockIdx.x * M;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n_tree = a.tree.n > 0 ? 1 : 0;
+    if ((int)blockIdx.x >= d.B / M + n_tree) {      // L2 warmers
+        const int sl = (blockIdx.x - (d.B / M + n_tree)) >> 3, nsl = (gridDim.x - (d.B / M + n_tree) + 7) >> 3;
+        unsigned acc = 0;
+        warm_layer(a.cf[0], sl, nsl, acc);
+        warm_layer(a.cf[1], sl, nsl, acc);
+        warm_layer(a.cf[2], sl, nsl, acc);
+        warm_layer(a.cb3, sl, nsl, acc);
+        warm_layer(a.cb2, sl, nsl, acc);
+        warm_layer(a.cb1, sl, nsl, acc);
+        warm_layer(a.ab3, sl, nsl, acc);
+        warm_layer(a.ab2, sl, nsl, acc);
+        asm volatile("" ::"v"(acc));
+        return;
+    }
     if (row0 >= d.B) {         // the extra workgroup
         tree_update_body<NW>(a.tree);
         return;
     }
     STAMP(1, 31);
-    Chain<MT, KSH, KSN> ch;
+    Chain<NW, MT, KSH, KSN> ch;
     ch.prefetch_n(a.cf[0]);
     int off = 0;
     auto carve = [&](int bytes) { char* p = smem + off; off += (bytes + 15) & ~15; return p; };
@@ -849,9 +916,9 @@ __global__ __launch_bounds__(64 * NW) void actor_phase_kernel(const ActorPhaseAr
     STAMP(1, 3);
     // ---- actor loss: -mean Q ----
     if (d.distributional && d.NO <= 64)
-        actor_rows<1, M>(a, row0, lane, wave, lg_o, dlg);
+        actor_rows<NW, 1, M>(a, row0, lane, wave, lg_o, dlg);
     else
-        actor_rows<4, M>(a, row0, lane, wave, lg_o, dlg);
+        actor_rows<NW, 4, M>(a, row0, lane, wave, lg_o, dlg);
     __syncthreads();
     STAMP(1, 4);
     // ---- critic backward (dX only) down to the action ----
@@ -902,16 +969,18 @@ __global__ __launch_bounds__(64 * NW) void actor_phase_kernel(const ActorPhaseAr
 
 // ---------------------------------------------------------------------------------------
 // host launchers
-static int phase_lds_bytes_critic(const PhaseDims& d, int M) {
+static int phase_lds_bytes_critic(const PhaseDims& d, int M, int nw) {
     auto al = [](int b) { return (b + 15) & ~15; };
     return 2 * al(M * d.ldx * 2) + 4 * al(M * d.ldh * 2) + al(M * d.ldd * 2) + 2 * al(M * d.nop * 4) +
-           2 * al(NW * 256 * 4) + al(4 * M * 4);
+           2 * al(nw * 256 * 4) + al(4 * M * 4);
 }
-static int phase_lds_bytes_actor(const PhaseDims& d, int M) {
+static int phase_lds_bytes_actor(const PhaseDims& d, int M, int) {
     auto al = [](int b) { return (b + 15) & ~15; };
     return al(M * d.ldx * 2) + 4 * al(M * d.ldh * 2) + al(M * d.ldd * 2) + al(M * d.lda_ * 2) + al(M * d.nop * 4) +
            al(M * 16 * ((d.A + 15) / 16) * 4);
 }
+// waves per workgroup for a batch of B rows in tiles of M: see NW_FEW
+static int phase_waves(const PhaseDims& d, int mt) { return (mt == 1 && d.B / 16 <= 128) ? NW_FEW : NW_MANY; }
 
 static int check_dims(const PhaseDims& d, int M) {
     if (d.B < M || d.B % M) return -1;
@@ -943,24 +1012,40 @@ static int max3i(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c 
 // hidden-K layers run the compile-time path: their K-steps must be the kernel's
 static int check_hidden(const LayerW& L, int ksh) { return L.ks == ksh ? 0 : -10; }
 
+// L2 warmer workgroups per phase launch (warm_l2_role): a multiple of 8, one slice per XCD each
+// Only while the grid leaves CUs idle: behind a grid that fills the chip the warmers are dispatched last
+// and just lengthen the launch (batch 4096: 97.8 -> 115.6 us).
+static int phase_waves(const PhaseDims& d, int mt);
+static int n_warmers(const PhaseDims& d, int mt) {
+    if (phase_waves(d, mt) != NW_FEW) return 0;
+    static const int n = [] {
+        const char* e = getenv("D4PG_L2_WARMERS");
+        // measured per update (batch 256 / 2048 / 256 with PER): 0: 63.5 / 72.1 / 72.6 us, 8: 63.3 / 76.3 / 73.0,
+        // 16: 60.5 / 70.5 / 69.5, 32: 59.6 / 69.9 / 69.2, 64: 59.7 / 69.7 / 69.5
+        const int v = e ? atoi(e) : 32;
+        return v < 0 ? 0 : (v > 256 ? 256 : (v + 7) & ~7);
+    }();
+    return n;
+}
+
 template <typename K, typename Args>
-static int launch_phase(K kernel, const Args& a, int grid, int lds, hipStream_t stream) {
+static int launch_phase(K kernel, const Args& a, int grid, int nw, int lds, hipStream_t stream) {
     if (lds > 160 * 1024) return -8;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * NW), lds, stream, a);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * nw), lds, stream, a);
     return (int)hipGetLastError();
 }
 
 // KSN: register block of the narrow-K layers (2 covers inputs / logits up to 64 wide)
-#define DISPATCH_KSH(KERNEL, MTV, KSNV)                                                        \
-    do {                                                                                       \
-        if (ksh == 13) return launch_phase(KERNEL<MTV, 13, KSNV>, *a, grid, lds, stream);      \
-        if (ksh == 4) return launch_phase(KERNEL<MTV, 4, KSNV>, *a, grid, lds, stream);        \
-        if (ksh == 8) return launch_phase(KERNEL<MTV, 8, KSNV>, *a, grid, lds, stream);        \
-        return launch_phase(KERNEL<MTV, 0, KSNV>, *a, grid, lds, stream);                      \
+#define DISPATCH_KSH(KERNEL, NWV, MTV, KSNV)                                                       \
+    do {                                                                                           \
+        if (ksh == 13) return launch_phase(KERNEL<NWV, MTV, 13, KSNV>, *a, grid, NWV, lds, stream); \
+        if (ksh == 4) return launch_phase(KERNEL<NWV, MTV, 4, KSNV>, *a, grid, NWV, lds, stream);   \
+        if (ksh == 8) return launch_phase(KERNEL<NWV, MTV, 8, KSNV>, *a, grid, NWV, lds, stream);   \
+        return launch_phase(KERNEL<NWV, MTV, 0, KSNV>, *a, grid, NWV, lds, stream);                 \
     } while (0)
 
 #define DISPATCH_PHASE(KERNEL, LDSFN)                                                       \
@@ -969,15 +1054,20 @@ static int launch_phase(K kernel, const Args& a, int grid, int lds, hipStream_t 
     if (mt != 1 && mt != 2) return -9;                                                      \
     int rc = check_dims(d, M);                                                              \
     if (rc) return rc;                                                                      \
-    const int lds = LDSFN(d, M);                                                            \
+    const int nw = phase_waves(d, mt);                                                      \
+    const int lds = LDSFN(d, M, nw);                                                        \
     const int grid = d.B / M + extra_blocks;                                                \
     const int ksh = (d.ldh - LDS_PAD) / 32;                                                 \
-    if (mt == 1) {                                                                          \
-        if (ksn <= 2) DISPATCH_KSH(KERNEL, 1, 2);                                           \
-        DISPATCH_KSH(KERNEL, 1, 4);                                                         \
+    if (nw == NW_FEW) {                                                                     \
+        if (ksn <= 2) DISPATCH_KSH(KERNEL, NW_FEW, 1, 2);                                   \
+        DISPATCH_KSH(KERNEL, NW_FEW, 1, 4);                                                 \
     }                                                                                       \
-    if (ksn <= 2) DISPATCH_KSH(KERNEL, 2, 2);                                               \
-    DISPATCH_KSH(KERNEL, 2, 4);
+    if (mt == 1) {                                                                          \
+        if (ksn <= 2) DISPATCH_KSH(KERNEL, NW_MANY, 1, 2);                                  \
+        DISPATCH_KSH(KERNEL, NW_MANY, 1, 4);                                                \
+    }                                                                                       \
+    if (ksn <= 2) DISPATCH_KSH(KERNEL, NW_MANY, 2, 2);                                      \
+    DISPATCH_KSH(KERNEL, NW_MANY, 2, 4);
 
 D4PG_API int d4pg_critic_phase(const CriticPhaseArgs* a, int mt, hipStream_t stream) {
     const int kmax = max_k32(a->d);
@@ -995,7 +1085,8 @@ D4PG_API int d4pg_critic_phase(const CriticPhaseArgs* a, int mt, hipStream_t str
         a->fwd.sT == nullptr || a->fwd.h1T == nullptr || a->fwd.h2T == nullptr)
         return -14;
     const int ksn = max3i(a->cb3.ks, a->ta[0].ks, max3i(a->tc[0].ks, a->cf[0].ks, a->fwd.af[0].ks));
-    const int extra_blocks = a->d.B / (mt == 2 ? 32 : 16);      // the actor forward pass rides along
+    // the actor forward pass rides along, then the L2 warmers
+    const int extra_blocks = a->d.B / (mt == 2 ? 32 : 16) + n_warmers(a->d, mt);
     if (int prc = check_packed(a->pk, a->d)) return prc;
     DISPATCH_PHASE(critic_phase_kernel, phase_lds_bytes_critic)
 }
@@ -1016,12 +1107,13 @@ D4PG_API int d4pg_actor_phase(const ActorPhaseArgs* a, int mt, hipStream_t strea
     if (a->tree.n < 0 || (a->tree.n > 0 && (a->tree.idx == nullptr || a->tree.prio == nullptr ||
                                             a->tree.t.L < 0 || a->tree.t.L > MAXL)))
         return -11;
-    const int extra_blocks = a->tree.n > 0 ? 1 : 0;
+    const int extra_blocks = (a->tree.n > 0 ? 1 : 0) + n_warmers(a->d, mt);
     DISPATCH_PHASE(actor_phase_kernel, phase_lds_bytes_actor)
 }
 
 D4PG_API int d4pg_phase_lds_bytes(const PhaseDims* d, int mt, int actor) {
-    return actor ? phase_lds_bytes_actor(*d, 16 * mt) : phase_lds_bytes_critic(*d, 16 * mt);
+    const int nw = phase_waves(*d, mt);
+    return actor ? phase_lds_bytes_actor(*d, 16 * mt, nw) : phase_lds_bytes_critic(*d, 16 * mt, nw);
 }
 
 // ---------------------------------------------------------------------------------------

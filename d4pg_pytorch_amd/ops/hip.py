@@ -19,7 +19,8 @@ from typing import Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libd4pg_hip.so")
+# D4PG_HIP_LIB: load another build of the library (kernel-variant A/B runs, bench/exp/build_variant.py)
+LIB_PATH = os.environ.get("D4PG_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libd4pg_hip.so")
 
 _lib: Optional[C.CDLL] = None
 

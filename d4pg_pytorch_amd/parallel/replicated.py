@@ -1,7 +1,7 @@
 """Replicated data parallelism: sharded replay, all-gathered batches, replicated update.
 
-One learner update of the 400-wide MLPs occupies 16 of the 256 compute units at batch 256
-and takes the same ~80 us at batch 512 or 1024 (92 us) — it is bound by the length of the
+One learner update of the 400-wide MLPs occupies 32 of the 256 compute units at batch 256
+(60 us) and takes 65 us at batch 1024 and 71 us at 2048 — it is bound by the length of the
 dependent layer chain, not by arithmetic.  Two gradient all-reduces of 0.7-0.9 MB per
 update (``attach_data_parallel`` in ``comm.py``) sit on exactly that critical path and are
 pure xGMI latency.  This mode removes them:
