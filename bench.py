@@ -21,7 +21,7 @@ Data-parallel modes (``--dp-mode``, N > 1):
   replicated      the sampled rows are all-gathered (one ~20 KB/rank collective, one update
                   ahead on a side stream) and every rank runs the update on the global
                   batch as ONE graph; no gradient traffic.  A learner update is latency
-                  bound, not throughput bound (60 us at batch 256, 65 us at 1024, 71 us at
+                  bound, not throughput bound (55 us at batch 256, 61 us at 1024, 67 us at
                   2048 on one MI355X), so replicating the arithmetic is cheaper than two
                   latency-bound gradient all-reduces on the critical path.
   grad_allreduce  every rank runs the update on its 256 rows and the critic and actor

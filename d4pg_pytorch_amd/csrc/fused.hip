@@ -379,8 +379,9 @@ struct RowSrc {
 __device__ __forceinline__ RowSrc plain_src(const float* base, long long stride, int B) {
     return RowSrc{base, stride, 0, B > 0 ? B : 1};
 }
-__device__ __forceinline__ RowSrc packed_src(const PackedIn& p, int col0) {
-    const long long s = p.st->step_done - p.step0;
+// delta = 1: the batch of the NEXT update
+__device__ __forceinline__ RowSrc packed_src(const PackedIn& p, int col0, int delta = 0) {
+    const long long s = p.st->step_done - p.step0 + delta;
     const int j = (int)(s % p.K);
     const float* chunk = ((s / p.K) & 1) ? p.in1 : p.in0;
     const long long ldp = p.row_ld + 4;
@@ -408,6 +409,23 @@ struct PhaseDims {
     float inv_B;         // 1 / global batch
     float min_value, max_value;   // scalar-critic target clamp
 };
+
+// The online critic's forward pass on the batch of update u + 1 needs nothing but that batch and
+// the critic weights as update u leaves them, and those are final once the critic optimiser of
+// update u has run.  When the batches are drawn ahead (PackedIn), B / M extra workgroups of the
+// actor phase launch of update u make that pass (critic_ahead_role) and leave its row tiles in
+// global memory; the critic phase of update u + 1 then starts from them and its dependent chain is
+// three layers shorter.  A tag in DevState names the update and the rows the tiles belong to, so
+// a critic phase that finds anything else (first update, another batch source, weights loaded by
+// the host in between) simply makes the pass itself.
+struct CriticAhead {
+    int mode;        // 0: off; 1: only while the next batch is in the same chunk buffer; 2: always
+    int pad_;
+    __bf16* h1;      // [B][ldh] relu(layer 1) row tiles (LDS images)
+    __bf16* h2;      // [B][ldh]
+    float* lg;       // [B][nop] logits
+};
+constexpr int AHEAD_STEP = 0, AHEAD_ROWS = 1;      // DevState::pad_ slots of the tag
 
 // The online actor's forward pass a = pi(s) does not depend on the critic update, so it does
 // not belong on the critical path critic phase -> critic optimiser -> actor phase: it runs in
@@ -448,6 +466,7 @@ struct CriticPhaseArgs {
     float* per_loss;
     float* priority;
     ActorFwd fwd;
+    CriticAhead ahead;     // tiles made by the previous update's actor phase launch (consumed when the tag matches)
 };
 
 // zero `bytes` (multiple of 16) of LDS
@@ -610,6 +629,42 @@ __device__ __forceinline__ void actor_forward_role(const CriticPhaseArgs& a, int
     copy16(f.g_pi + (size_t)row0 * ldpi, pi, M * ldpi * 4);
 }
 
+// Everything after the logits of both critics: loss rows, then the backward pass through critic
+// layers 3 and 2.  A function called once per branch of the kernel (and not code after the branches
+// join): registers holding prefetched weights must not be merged where two control-flow paths meet.
+template <int NW, int MT, int KSH, int KSN>
+__device__ __forceinline__ void critic_tail(const CriticPhaseArgs& a, Chain<NW, MT, KSH, KSN>& ch, int row0, int lane,
+                                            int wave, const float* lg_t, const float* lg_o, __bf16* dlg, float* sp,
+                                            float* sb, const float* rs, __bf16* bufC, __bf16* bufD) {
+    constexpr int M = 16 * MT;
+    const PhaseDims& d = a.d;
+    __syncthreads();
+    STAMP(0, 9);
+    // ---- loss: one wave per row ----
+    if (d.distributional && d.NO <= 64)
+        critic_rows<NW, 1, M>(a, row0, lane, wave, lg_t, lg_o, dlg, sp, sb, rs);
+    else
+        critic_rows<NW, 4, M>(a, row0, lane, wave, lg_t, lg_o, dlg, sp, sb, rs);
+    __syncthreads();
+    STAMP(0, 10);
+    // ---- backward through critic layers 3 and 2 (activation gradients only) ----
+    ch.narrow(dlg, d.ldd, a.cb3, [=](int r0, int col, f32x4 v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (float)bufD[(r0 + r) * d.ldh + col] > 0.f ? v[r] : 0.f;
+        put_lds4(bufD, d.ldh, r0, col, v);       // in place: each element is read and written by one lane
+        put_stash4(a.dh2T, d.Bp, col, row0 + r0, v);
+    }, [&] { ch.template prefetch_h<0>(a.cb2); });
+    __syncthreads();
+    STAMP(0, 11);
+    ch.template hidden<0>(bufD, d.ldh, a.cb2, [=](int r0, int col, f32x4 v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (float)bufC[(r0 + r) * d.ldh + col] > 0.f ? v[r] : 0.f;
+        put_stash4(a.dh1T, d.Bp, col, row0 + r0, v);
+    }, [] {});
+    STAMP_SYNC();
+    STAMP(0, 12);
+}
+
 template <int NW, int MT, int KSH, int KSN>
 __global__ __launch_bounds__(64 * NW) void critic_phase_kernel(const CriticPhaseArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -691,10 +746,22 @@ __global__ __launch_bounds__(64 * NW) void critic_phase_kernel(const CriticPhase
     zero_block(dlg, M * d.ldd * 2);
     zero_tail(bufA, d.ldh, M, d.H);
     zero_tail(bufB, d.ldh, M, d.H);
-    zero_tail(bufC, d.ldh, M, d.H);
-    zero_tail(bufD, d.ldh, M, d.H);
+    // Was the online critic's forward pass on exactly these rows made ahead, after the last change
+    // of the critic weights?  (wave-uniform; see CriticAhead)
+    bool ahead_ok = false;
+    if (a.ahead.mode != 0 && a.pk.enabled)
+        ahead_ok = a.pk.st->pad_[AHEAD_STEP] == a.pk.st->step_done + 1 &&
+                   a.pk.st->pad_[AHEAD_ROWS] == (long long)(uintptr_t)src_sa.base;
     STAMP(0, 0);
-    load_input(src_sa, row0, M, SA, xin, d.ldx, a.saT, d.Bp);
+    if (ahead_ok) {
+        copy16(bufC, a.ahead.h1 + (size_t)row0 * d.ldh, M * d.ldh * 2);
+        copy16(bufD, a.ahead.h2 + (size_t)row0 * d.ldh, M * d.ldh * 2);
+        copy16(lg_o, a.ahead.lg + (size_t)row0 * d.nop, M * d.nop * 4);
+    } else {
+        zero_tail(bufC, d.ldh, M, d.H);
+        zero_tail(bufD, d.ldh, M, d.H);
+        load_input(src_sa, row0, M, SA, xin, d.ldx, a.saT, d.Bp);
+    }
     load_input(src_s2, row0, M, d.S, xin2, d.ldx, nullptr, 0);
     if (threadIdx.x < M) {
         rs[threadIdx.x] = rs_r;
@@ -735,60 +802,49 @@ __global__ __launch_bounds__(64 * NW) void critic_phase_kernel(const CriticPhase
     ch.template hidden<0>(bufA, d.ldh, a.tc[1], relu_to(bufB), [&] { ch.template prefetch_h<1>(a.tc[2]); });
     __syncthreads();
     STAMP(0, 6);
-    ch.template hidden<1>(bufB, d.ldh, a.tc[2], [=](int r0, int col, f32x4 v) {
+    auto to_lg_t = [=](int r0, int col, f32x4 v) {
         if (col < d.nop) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) lg_t[(r0 + r) * d.nop + col] = v[r];
         }
-    }, [&] { ch.prefetch_n(a.cf[0]); });
-    // ---- online critic: (s, a) -> logits, activations stashed (transposed) for wgrad ----
-    ch.narrow(xin, d.ldx, a.cf[0], [=](int r0, int col, f32x4 v) {
+    };
+    // With the online critic's tiles made ahead, its three layers are skipped.  The first of them is
+    // prefetched by the layer before; skipping is expressed as a layer without tiles, with the fields
+    // selected one by one: a POINTER into the kernel arguments that depends on a run-time condition
+    // makes the compiler keep a copy of all the arguments in scratch memory (so does a second call
+    // site of the code after the branch, which is why that code is not duplicated into the branches).
+    LayerW after_tc = a.cf[0];
+    after_tc.ntiles = ahead_ok ? 0 : a.cf[0].ntiles;
+    ch.template hidden<1>(bufB, d.ldh, a.tc[2], to_lg_t, [&] { ch.prefetch_n(after_tc); });
+    if (!ahead_ok) {
+        // ---- online critic: (s, a) -> logits, activations stashed (transposed) for wgrad ----
+        ch.narrow(xin, d.ldx, a.cf[0], [=](int r0, int col, f32x4 v) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-        put_lds4(bufC, d.ldh, r0, col, v);
-        put_stash4(a.h1T, d.Bp, col, row0 + r0, v);
-    }, [&] { ch.template prefetch_h<0>(a.cf[1]); });
-    __syncthreads();
-    STAMP(0, 7);
-    ch.template hidden<0>(bufC, d.ldh, a.cf[1], [=](int r0, int col, f32x4 v) {
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            put_lds4(bufC, d.ldh, r0, col, v);
+            put_stash4(a.h1T, d.Bp, col, row0 + r0, v);
+        }, [&] { ch.template prefetch_h<0>(a.cf[1]); });
+        __syncthreads();
+        STAMP(0, 7);
+        ch.template hidden<0>(bufC, d.ldh, a.cf[1], [=](int r0, int col, f32x4 v) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-        put_lds4(bufD, d.ldh, r0, col, v);
-        put_stash4(a.h2T, d.Bp, col, row0 + r0, v);
-    }, [&] { ch.template prefetch_h<1>(a.cf[2]); });
-    __syncthreads();
-    STAMP(0, 8);
-    ch.template hidden<1>(bufD, d.ldh, a.cf[2], [=](int r0, int col, f32x4 v) {
-        if (col < d.nop) {
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            put_lds4(bufD, d.ldh, r0, col, v);
+            put_stash4(a.h2T, d.Bp, col, row0 + r0, v);
+        }, [&] { ch.template prefetch_h<1>(a.cf[2]); });
+        __syncthreads();
+        STAMP(0, 8);
+        ch.template hidden<1>(bufD, d.ldh, a.cf[2], [=](int r0, int col, f32x4 v) {
+            if (col < d.nop) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) lg_o[(r0 + r) * d.nop + col] = v[r];
-        }
-    }, [&] { ch.prefetch_n(a.cb3); });
-    __syncthreads();
-    STAMP(0, 9);
-    // ---- loss: one wave per row ----
-    if (d.distributional && d.NO <= 64)
-        critic_rows<NW, 1, M>(a, row0, lane, wave, lg_t, lg_o, dlg, sp, sb, rs);
-    else
-        critic_rows<NW, 4, M>(a, row0, lane, wave, lg_t, lg_o, dlg, sp, sb, rs);
-    __syncthreads();
-    STAMP(0, 10);
-    // ---- backward through critic layers 3 and 2 (activation gradients only) ----
-    ch.narrow(dlg, d.ldd, a.cb3, [=](int r0, int col, f32x4 v) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = (float)bufD[(r0 + r) * d.ldh + col] > 0.f ? v[r] : 0.f;
-        put_lds4(bufD, d.ldh, r0, col, v);       // in place: each element is read and written by one lane
-        put_stash4(a.dh2T, d.Bp, col, row0 + r0, v);
-    }, [&] { ch.template prefetch_h<0>(a.cb2); });
-    __syncthreads();
-    STAMP(0, 11);
-    ch.template hidden<0>(bufD, d.ldh, a.cb2, [=](int r0, int col, f32x4 v) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = (float)bufC[(r0 + r) * d.ldh + col] > 0.f ? v[r] : 0.f;
-        put_stash4(a.dh1T, d.Bp, col, row0 + r0, v);
-    }, [] {});
-    STAMP_SYNC();
-    STAMP(0, 12);
+                for (int r = 0; r < 4; ++r) lg_o[(r0 + r) * d.nop + col] = v[r];
+            }
+        }, [] {});
+    }
+    // No prefetched registers are live where the two paths join: the first backward layer is fetched
+    // here and lands while the loss rows are computed.
+    ch.prefetch_n(a.cb3);
+    critic_tail<NW, MT, KSH, KSN>(a, ch, row0, lane, wave, lg_t, lg_o, dlg, sp, sb, rs, bufC, bufD);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -811,7 +867,64 @@ struct ActorPhaseArgs {
     // critic phase wrote, and must be finished before the next update samples.  Forking it
     // onto a second stream inside the graph instead costs ~10 us per cross-queue dependency.
     TreeUpdateArgs tree;   // tree.n == 0: none
+    // The online critic's forward pass for the NEXT update, in B / M more workgroups (CriticAhead)
+    PackedIn pk;           // where the batches are (ahead.mode != 0 needs pk.enabled)
+    __bf16* c_saT;         // the critic's input / activation stashes for its weight gradients
+    __bf16* c_h1T;
+    __bf16* c_h2T;
+    CriticAhead ahead;
 };
+
+template <int NW, int MT, int KSH, int KSN>
+__device__ __forceinline__ void critic_ahead_role(const ActorPhaseArgs& a, int row0, char* smem) {
+    constexpr int M = 16 * MT;
+    const PhaseDims& d = a.d;
+    const long long s_next = a.pk.st->step_done - a.pk.step0 + 1;
+    // mode 1: the next chunk buffer may still be receiving its rows (all-gather on another stream)
+    if (a.ahead.mode == 1 && s_next % a.pk.K == 0) return;
+    Chain<NW, MT, KSH, KSN> ch;
+    ch.prefetch_n(a.cf[0]);
+    int off = 0;
+    auto carve = [&](int bytes) { char* p = smem + off; off += (bytes + 15) & ~15; return p; };
+    __bf16* xin = (__bf16*)carve(M * d.ldx * 2);    // [s | a]
+    __bf16* bufC = (__bf16*)carve(M * d.ldh * 2);   // h1
+    __bf16* bufD = (__bf16*)carve(M * d.ldh * 2);   // h2
+    float* lg = (float*)carve(M * d.nop * 4);
+    zero_tail(bufC, d.ldh, M, d.H);
+    zero_tail(bufD, d.ldh, M, d.H);
+    const RowSrc src = packed_src(a.pk, 0, 1);
+    load_input(src, row0, M, d.S + d.A, xin, d.ldx, a.c_saT, d.Bp);
+    __syncthreads();
+    ch.narrow(xin, d.ldx, a.cf[0], [=](int r0, int col, f32x4 v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        put_lds4(bufC, d.ldh, r0, col, v);
+        put_stash4(a.c_h1T, d.Bp, col, row0 + r0, v);
+    }, [&] { ch.template prefetch_h<0>(a.cf[1]); });
+    __syncthreads();
+    copy16(a.ahead.h1 + (size_t)row0 * d.ldh, bufC, M * d.ldh * 2);
+    ch.template hidden<0>(bufC, d.ldh, a.cf[1], [=](int r0, int col, f32x4 v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        put_lds4(bufD, d.ldh, r0, col, v);
+        put_stash4(a.c_h2T, d.Bp, col, row0 + r0, v);
+    }, [&] { ch.template prefetch_h<1>(a.cf[2]); });
+    __syncthreads();
+    copy16(a.ahead.h2 + (size_t)row0 * d.ldh, bufD, M * d.ldh * 2);
+    ch.template hidden<1>(bufD, d.ldh, a.cf[2], [=](int r0, int col, f32x4 v) {
+        if (col < d.nop) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lg[(r0 + r) * d.nop + col] = v[r];
+        }
+    }, [] {});
+    __syncthreads();
+    copy16(a.ahead.lg + (size_t)row0 * d.nop, lg, M * d.nop * 4);
+    // the tag: which update and which rows these tiles are for (read by the next launch)
+    if (row0 == 0 && threadIdx.x == 0) {
+        a.pk.st->pad_[AHEAD_STEP] = a.pk.st->step_done + 2;
+        a.pk.st->pad_[AHEAD_ROWS] = (long long)(uintptr_t)src.base;
+    }
+}
 
 template <int NW, int SL, int M>
 __device__ __forceinline__ void actor_rows(const ActorPhaseArgs& a, int row0, int lane, int wave, const float* lg_o,
@@ -849,8 +962,9 @@ __global__ __launch_bounds__(64 * NW) void actor_phase_kernel(const ActorPhaseAr
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n_tree = a.tree.n > 0 ? 1 : 0;
-    if ((int)blockIdx.x >= d.B / M + n_tree) {      // L2 warmers
-        const int sl = (blockIdx.x - (d.B / M + n_tree)) >> 3, nsl = (gridDim.x - (d.B / M + n_tree) + 7) >> 3;
+    const int n_work = d.B / M + n_tree + (a.ahead.mode != 0 ? d.B / M : 0);
+    if ((int)blockIdx.x >= n_work) {                // L2 warmers
+        const int sl = (blockIdx.x - n_work) >> 3, nsl = (gridDim.x - n_work + 7) >> 3;
         unsigned acc = 0;
         warm_layer(a.cf[0], sl, nsl, acc);
         warm_layer(a.cf[1], sl, nsl, acc);
@@ -861,6 +975,10 @@ __global__ __launch_bounds__(64 * NW) void actor_phase_kernel(const ActorPhaseAr
         warm_layer(a.ab3, sl, nsl, acc);
         warm_layer(a.ab2, sl, nsl, acc);
         asm volatile("" ::"v"(acc));
+        return;
+    }
+    if ((int)blockIdx.x >= d.B / M + n_tree) {      // the online critic's forward pass of the next update
+        critic_ahead_role<NW, MT, KSH, KSN>(a, (blockIdx.x - (d.B / M + n_tree)) * M, smem);
         return;
     }
     if (row0 >= d.B) {         // the extra workgroup
@@ -1088,6 +1206,7 @@ D4PG_API int d4pg_critic_phase(const CriticPhaseArgs* a, int mt, hipStream_t str
     // the actor forward pass rides along, then the L2 warmers
     const int extra_blocks = a->d.B / (mt == 2 ? 32 : 16) + n_warmers(a->d, mt);
     if (int prc = check_packed(a->pk, a->d)) return prc;
+    if (a->ahead.mode != 0 && (a->ahead.h1 == nullptr || a->ahead.h2 == nullptr || a->ahead.lg == nullptr)) return -15;
     DISPATCH_PHASE(critic_phase_kernel, phase_lds_bytes_critic)
 }
 
@@ -1107,7 +1226,15 @@ D4PG_API int d4pg_actor_phase(const ActorPhaseArgs* a, int mt, hipStream_t strea
     if (a->tree.n < 0 || (a->tree.n > 0 && (a->tree.idx == nullptr || a->tree.prio == nullptr ||
                                             a->tree.t.L < 0 || a->tree.t.L > MAXL)))
         return -11;
-    const int extra_blocks = (a->tree.n > 0 ? 1 : 0) + n_warmers(a->d, mt);
+    if (a->ahead.mode != 0) {
+        if (a->ahead.mode < 0 || a->ahead.mode > 2 || !a->pk.enabled) return -15;
+        if (a->ahead.h1 == nullptr || a->ahead.h2 == nullptr || a->ahead.lg == nullptr || a->c_saT == nullptr ||
+            a->c_h1T == nullptr || a->c_h2T == nullptr)
+            return -15;
+        if (int prc = check_packed(a->pk, a->d)) return prc;
+    }
+    const int n_ahead = a->ahead.mode != 0 ? a->d.B / (mt == 2 ? 32 : 16) : 0;
+    const int extra_blocks = (a->tree.n > 0 ? 1 : 0) + n_ahead + n_warmers(a->d, mt);
     DISPATCH_PHASE(actor_phase_kernel, phase_lds_bytes_actor)
 }
 

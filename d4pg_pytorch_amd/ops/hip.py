@@ -178,12 +178,16 @@ class ActorFwd(C.Structure):
                 ("g_xin", vp), ("g_h1", vp), ("g_h2", vp), ("g_pi", vp)]
 
 
+class CriticAhead(C.Structure):
+    _fields_ = [("mode", C.c_int), ("pad_", C.c_int), ("h1", vp), ("h2", vp), ("lg", vp)]
+
+
 class CriticPhaseArgs(C.Structure):
     _fields_ = [("d", PhaseDims), ("sa", vp), ("s2", vp), ("reward", vp), ("done", vp), ("gamma", vp),
                 ("weights", vp), ("pk", PackedIn), ("ta", LayerW * 3), ("tc", LayerW * 3), ("cf", LayerW * 3),
                 ("cb3", LayerW), ("cb2", LayerW),
                 ("saT", vp), ("h1T", vp), ("h2T", vp), ("dlT", vp), ("dh2T", vp), ("dh1T", vp),
-                ("per_loss", vp), ("priority", vp), ("fwd", ActorFwd)]
+                ("per_loss", vp), ("priority", vp), ("fwd", ActorFwd), ("ahead", CriticAhead)]
 
 
 class ActorPhaseArgs(C.Structure):
@@ -191,7 +195,8 @@ class ActorPhaseArgs(C.Structure):
                 ("cf", LayerW * 3),
                 ("cb3", LayerW), ("cb2", LayerW), ("cb1", LayerW), ("ab3", LayerW), ("ab2", LayerW),
                 ("daT", vp), ("dh2T", vp), ("dh1T", vp), ("q_val", vp),
-                ("tree", TreeUpdateArgs)]
+                ("tree", TreeUpdateArgs), ("pk", PackedIn), ("c_saT", vp), ("c_h1T", vp), ("c_h2T", vp),
+                ("ahead", CriticAhead)]
 
 
 class WgradDesc(C.Structure):

@@ -1,7 +1,7 @@
 """Replicated data parallelism: sharded replay, all-gathered batches, replicated update.
 
 One learner update of the 400-wide MLPs occupies 32 of the 256 compute units at batch 256
-(60 us) and takes 65 us at batch 1024 and 71 us at 2048 — it is bound by the length of the
+(55 us) and takes 61 us at batch 1024 and 67 us at 2048 — it is bound by the length of the
 dependent layer chain, not by arithmetic.  Two gradient all-reduces of 0.7-0.9 MB per
 update (``attach_data_parallel`` in ``comm.py``) sit on exactly that critical path and are
 pure xGMI latency.  This mode removes them:
@@ -74,7 +74,10 @@ class ReplicatedDP:
             prio_args = replay.priority_update_args(core.idx[sl], core.prio[sl], self.Bl)
         # [unpack +] update [+ priority write-back]: ONE captured graph serves every update
         if core.supports_direct_input and not replay.prioritized:
-            core.register_direct("gathered", self.bufs[0], self.bufs[1], replay.row_ld, self.Bl, self.K)
+            # the next chunk buffer is filled on this stream (one rank) or by an all-gather on the side
+            # stream that the main stream only waits for when it starts consuming that chunk (several)
+            core.register_direct("gathered", self.bufs[0], self.bufs[1], replay.row_ld, self.Bl, self.K,
+                                 critic_ahead=2 if self.world == 1 else 1)
         else:
             core.register_packed("gathered", self.bufs[0], self.bufs[1], replay.row_ld, self.Bl, self.K, prio_args)
 
