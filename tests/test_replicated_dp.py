@@ -151,3 +151,42 @@ def test_rccl_world_one_all_gather_wiring():
         assert dp.check_consistency() == 0.0
     finally:
         comm.close()
+
+
+def test_critic_forward_made_ahead_is_tagged_and_dropped_when_weights_change(monkeypatch):
+    """The actor-phase launch of update u also makes the online critic's forward pass for the batch of
+    update u + 1 (bf16 pipeline, drawn-ahead batches).  The hand-off carries a tag in the device state
+    (update ordinal + address of the rows); a host-side change of the weights clears it, so the next
+    critic phase makes the pass itself.  With and without the hand-off the parameters are bit-identical."""
+    from d4pg_pytorch_amd.models.core import build_core
+    from d4pg_pytorch_amd.replay.hbm_replay import HbmReplay
+    outs = {}
+    for mode in ("ahead", "inline"):
+        monkeypatch.setenv("D4PG_CRITIC_AHEAD", "1" if mode == "ahead" else "0")
+        cfg = dict(_cfg(256), sample_ahead=4)
+        core = build_core(cfg, "cuda")
+        rp = HbmReplay(cfg, "cuda", core.dev_state)
+        rp.insert(_rows(rp, 20_000, 3))
+        core.attach_replay(rp)
+        for _ in range(5):                      # crosses a chunk boundary (4 batches per chunk)
+            core.update_from_replay()
+        torch.cuda.synchronize()
+        st = core.read_dev_state()
+        assert st.step_done == 5
+        if mode == "ahead":
+            assert core.direct_ahead.get("gathered") == 2
+            assert st.pad_[0] == 6 and st.pad_[1] != 0          # tiles for update 6 are waiting
+        else:
+            assert st.pad_[0] == 0
+        with torch.no_grad():                   # the host changes the weights: the tiles are stale
+            core.online.flat.mul_(0.97)
+        core.refresh_shadows()
+        assert core.read_dev_state().pad_[0] == 0
+        done = 0
+        while done < 7:
+            done += core.update_from_replay_many(7 - done)
+        torch.cuda.synchronize()
+        assert core.read_dev_state().step_done == 12
+        outs[mode] = (core.online.flat.clone(), core.target.flat.clone(), core.adam_v.clone())
+    for a, b in zip(outs["ahead"], outs["inline"]):
+        assert torch.equal(a, b)
