@@ -59,6 +59,12 @@ def main():
     out["loss_detail_last_iter"] = {"cf3_barrier_to_row0_start": (v[16] - v[9]) / 100.0, "row0_math": (v[17] - v[16]) / 100.0,
                                     "row0_stores": (v[18] - v[17]) / 100.0, "row1_total": (v[19] - v[18]) / 100.0,
                                     "row1_end_to_barrier": (v[10] - v[19]) / 100.0}
+    # weight-gradient kernel (the actor's: last launch of the update), workgroup 0 / wave 0
+    out["wgrad_last_iter"] = {"entry_to_state_prefetch_issued": (v[32 + 21] - v[32 + 20]) / 100.0,
+                              "stash_loads_and_mfma": (v[32 + 22] - v[32 + 21]) / 100.0,
+                              "lds_write_and_barrier": (v[32 + 23] - v[32 + 22]) / 100.0,
+                              "reduce_adam_stores_issued": (v[32 + 24] - v[32 + 23]) / 100.0,
+                              "actor_phase_end_to_wgrad_entry": (v[32 + 20] - v[32 + 9]) / 100.0}
     for names, r, key in ((CRITIC, acc[0], "critic_phase"), (ACTOR, acc[1], "actor_phase")):
         out[key] = {nm: round(x / n, 2) for nm, x in zip(names, r)}
         out[key]["total_us"] = round(sum(r) / n, 2)

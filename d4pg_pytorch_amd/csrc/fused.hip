@@ -1331,6 +1331,43 @@ __device__ __forceinline__ float adam_elem(const WgradAdam& o, long long idx, fl
     return p;
 }
 
+// End of an update: fold its losses into the metric sums and publish the step (step_done is read
+// only by the first kernel of the next update).  Run by ONE EXTRA workgroup of the finishing launch,
+// from its start: in a workgroup that also owns a tile this is ~1 us at the very end of the kernel.
+template <int NWV>
+__device__ __forceinline__ void wgrad_finish_role(const WgradAdam& o, float* cs) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // fold this update's losses into the metric sums and publish the step
+    // (step_done is read only by the first kernel of the next update)
+    __syncthreads();
+    float vl = 0.f, pl = 0.f;
+    for (int b = threadIdx.x; b < o.B; b += blockDim.x) {
+        vl += o.per_loss[b] * (o.weights ? o.weights[b] : 1.f);
+        pl -= o.q_val[b];
+    }
+    vl = wave_sum(vl);
+    pl = wave_sum(pl);
+    if (lane == 0) {
+        cs[wave] = vl;
+        cs[NWV + wave] = pl;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (o.metrics != nullptr) {
+            float svl = 0.f, spl = 0.f;
+            for (int w = 0; w < NWV; ++w) {
+                svl += cs[w];
+                spl += cs[NWV + w];
+            }
+            o.metrics[MET_VALUE_LOSS] += svl * o.inv_B;
+            o.metrics[MET_POLICY_LOSS] += spl * o.inv_B;
+            o.metrics[MET_COUNT] += 1.f;
+        }
+        o.st->step_done = o.st->step_cur;
+    }
+}
+
 // NWV waves split the batch (K); waves 0..3 then finish the tile (sum of the NWV partial
 // tiles, optimiser, shadows).  More waves = more stash loads in flight per CU: the loop is
 // bound by the latency of those loads (the stashes were just written by other CUs), so NWV
@@ -1342,6 +1379,11 @@ __global__ __launch_bounds__(64 * NWV) void wgrad_kernel(const WgradGroup g) {
     float* cs = wg_smem + NWV * 16 * 64;       // [NWV][32] partial row sums
     const int total = g.total_tiles;
     const int id = blockIdx.x;
+    if (id >= total) {          // the extra workgroup of a finishing launch
+        wgrad_finish_role<NWV>(g.opt, cs);
+        return;
+    }
+    STAMP(1, 20);
     const int xcd = id & 7, local = id >> 3;
     const int q = total >> 3, rem = total & 7;
     const int tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + local;
@@ -1377,6 +1419,7 @@ __global__ __launch_bounds__(64 * NWV) void wgrad_kernel(const WgradGroup g) {
     }
     const int per = (ksteps + NWV - 1) / NWV;
     const int k0 = wave * per, k1 = min(ksteps, k0 + per);
+    STAMP(1, 21);
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -1396,6 +1439,7 @@ __global__ __launch_bounds__(64 * NWV) void wgrad_kernel(const WgradGroup g) {
             for (int j = 0; j < 8; ++j) asum += (float)av[j];
         }
     }
+    STAMP(1, 22);
 #pragma unroll
     for (int i = 0; i < 16; ++i) red[(wave * 16 + i) * 64 + lane] = acc[i];
     if (want_rowsum) {
@@ -1403,6 +1447,7 @@ __global__ __launch_bounds__(64 * NWV) void wgrad_kernel(const WgradGroup g) {
         if (lane < 32) cs[wave * 32 + lane] = asum;
     }
     __syncthreads();
+    STAMP(1, 23);
     if (wave < 4) {
         if (fuse) {
             step_size = o.lr / step_size;
@@ -1462,36 +1507,7 @@ __global__ __launch_bounds__(64 * NWV) void wgrad_kernel(const WgradGroup g) {
                 }
             }
         }
-    }
-    if (fuse && o.finish_step && blockIdx.x == 0) {
-        // fold this update's losses into the metric sums and publish the step
-        // (step_done is read only by the first kernel of the next update)
-        __syncthreads();
-        float vl = 0.f, pl = 0.f;
-        for (int b = threadIdx.x; b < o.B; b += blockDim.x) {
-            vl += o.per_loss[b] * (o.weights ? o.weights[b] : 1.f);
-            pl -= o.q_val[b];
-        }
-        vl = wave_sum(vl);
-        pl = wave_sum(pl);
-        if (lane == 0) {
-            cs[wave] = vl;
-            cs[NWV + wave] = pl;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            if (o.metrics != nullptr) {
-                float svl = 0.f, spl = 0.f;
-                for (int w = 0; w < NWV; ++w) {
-                    svl += cs[w];
-                    spl += cs[NWV + w];
-                }
-                o.metrics[MET_VALUE_LOSS] += svl * o.inv_B;
-                o.metrics[MET_POLICY_LOSS] += spl * o.inv_B;
-                o.metrics[MET_COUNT] += 1.f;
-            }
-            o.st->step_done = o.st->step_cur;
-        }
+        STAMP(1, 24);
     }
 }
 
@@ -1502,7 +1518,8 @@ static int launch_wgrad(K kernel, int nwv, int grid, const WgradGroup& g, hipStr
         hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * nwv), lds, stream, g);
+    const int extra = (g.opt.p != nullptr && g.opt.finish_step) ? 1 : 0;       // wgrad_finish_role
+    hipLaunchKernelGGL(kernel, dim3(grid + extra), dim3(64 * nwv), lds, stream, g);
     return (int)hipGetLastError();
 }
 
