@@ -53,7 +53,7 @@ def main():
         for k, names in ((0, CRITIC), (1, ACTOR)):
             t = [v[k * 32 + 31]] + [v[k * 32 + i] for i in range(len(names))]
             if k == 0 and t[8] < t[7]:     # the online critic's layers were made ahead: stamps 7 and 8 not taken
-                t[8] = t[9] = t[7]         # "tc3+cf1" becomes tc3 alone, cf2 and cf3 read 0
+                t[8] = t[9] = t[7]         # "tc3+cf1" and "cf2" read 0, "cf3" is the target critic's last layer
             rows.append([(t[i + 1] - t[i]) / 100.0 for i in range(len(names))])
         acc = rows if acc is None else [[a + b for a, b in zip(ra, rb)] for ra, rb in zip(acc, rows)]
         n += 1
