@@ -73,6 +73,9 @@ def parse_args():
     ap.add_argument("--tile-rows", default="auto", choices=["auto", "16", "32"])
     ap.add_argument("--dp-mode", default="both", choices=["both", "replicated", "grad_allreduce"],
                     help="data-parallel scheme for N > 1 (see the module docstring)")
+    ap.add_argument("--chunk", type=int, default=0,
+                    help="updates per drawn-ahead chunk of batches = per graph replay (and per all-gather for N > 1); "
+                         "0: the configuration default (sample_ahead)")
     ap.add_argument("--dp-selftest", action="store_true",
                     help="with one GPU: run the N > 1 code path (both data-parallel modes) over a world-size-1 "
                          "RCCL group, to check the wiring on a single-GPU box")
@@ -131,6 +134,8 @@ def main() -> None:
                          replay_memory_prioritized=int(args.per), use_hip_graph=not args.no_graph,
                          compute_dtype=args.dtype, phase_tile_rows=args.tile_rows, num_steps_train=max(1, args.steps + args.warmup),
                          fused_learner="torch" if args.baseline else "auto", random_seed=2019)
+    if args.chunk > 0:
+        cfg["sample_ahead"] = args.chunk
     S, A = cfg["state_dim"], cfg["action_dim"]
     gamma_n = cfg["discount_rate"] ** cfg["n_step_returns"]
 
@@ -196,7 +201,7 @@ def main() -> None:
             core = build_core(dict(cfg, batch_size=args.batch * world), device)
             replay = HbmReplay(cfg, device, core.dev_state)
             fill(replay)
-            dp = attach_replicated(core, replay, comm, args.batch)
+            dp = attach_replicated(core, replay, comm, args.batch, chunk=int(cfg["sample_ahead"]))
             t = timed(dp.update, dp.update_many)
             drift = dp.check_consistency()
             assert drift == 0.0, f"learner replicas diverged (checksum difference {drift})"

@@ -103,7 +103,8 @@ EXTENSION_DEFAULTS: Dict[str, Any] = {
     "ingest_chunk": 1024,            # rows per pinned H2D staging chunk
     "ingest_interval": 32,           # learner updates between two drains of the explorer rings
     "phase_tile_rows": "auto",       # bf16 pipeline: batch rows per workgroup, "auto" | 16 | 32
-    "sample_ahead": 8,               # uniform replay, bf16 pipeline: batches drawn per sampling launch (1: every update)
+    "sample_ahead": 32,              # uniform replay, bf16 pipeline: batches drawn per sampling launch = updates per
+                                     # graph replay (1: every update); 8: 55.3 us per update, 32: 54.4 us
     # --- lifecycle ---
     "resume": None,                  # path to a learner checkpoint bundle to resume from
     "learner_checkpoint_interval": 0,  # 0 = only at the end

@@ -199,7 +199,9 @@ class Learner:
         dp = None
         if self.replicated:
             from ..parallel.replicated import attach_replicated
-            dp = attach_replicated(core, replay, self.comm, int(cfg["batch_size"]))
+            # prioritised replay: priorities lag by one to two chunks, so keep the chunks short
+            chunk = int(cfg["sample_ahead"]) if not replay.prioritized else min(8, int(cfg["sample_ahead"]))
+            dp = attach_replicated(core, replay, self.comm, int(cfg["batch_size"]), chunk=max(1, chunk))
         else:
             core.attach_replay(replay)
         self.replay = replay

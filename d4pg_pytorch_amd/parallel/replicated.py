@@ -9,9 +9,9 @@ pure xGMI latency.  This mode removes them:
 * every rank keeps its own HBM replay shard and priority tree, fed by its own explorers,
   and draws ``B`` rows per update from it (``HbmReplay.enqueue_sample_rows``);
 * the drawn rows (``B x (2S+A+7)`` floats, ~20 KB at batch 256) are all-gathered over RCCL,
-  ``K`` batches (a chunk, default 8) per collective, on a side stream while the previous
-  chunk is being consumed: one ~160 KB/rank collective and one cross-stream event pair per
-  8 updates (a cross-stream event wait + record around every graph replay costs ~14 us);
+  ``K`` batches (a chunk; 32 for uniform replay, 8 with priorities) per collective, on a side stream while the previous
+  chunk is being consumed: one ~0.6 MB/rank collective and one cross-stream event pair per
+  chunk (a cross-stream event wait + record around every graph replay costs ~14 us);
 * every rank then runs the SAME update on the global batch ``world x B`` with the
   single-graph fused pipeline (no gradient exchange, optimiser fused into the
   weight-gradient kernel).  The kernels are deterministic and the inputs identical, so
