@@ -698,7 +698,7 @@ __global__ __launch_bounds__(64 * NW) void critic_phase_kernel(const CriticPhase
         // thread, microseconds) runs in a workgroup that finishes long before the critic role does.
         // It reads step_done (like packed_src) and writes step_cur / bc1 / bc2 / per_beta, which
         // nothing in this launch reads.
-        if (a.pk.enabled && a.pk.do_tick && row0 == d.B && threadIdx.x == 0)
+        if (a.pk.do_tick && row0 == d.B && threadIdx.x == 0)
             devstate_tick(a.pk.st, a.pk.beta1, a.pk.beta2, a.pk.per_b0, a.pk.per_b1, a.pk.total_steps);
         actor_forward_role<NW, MT, KSH, KSN>(a, row0 - d.B, smem);
         return;
@@ -1121,6 +1121,7 @@ static int check_layer(const LayerW& L, int k32_max) {
     return 0;
 }
 static int check_packed(const PackedIn& p, const PhaseDims& d) {
+    if (p.do_tick && p.st == nullptr) return -12;
     if (!p.enabled) return 0;
     if (p.in0 == nullptr || p.in1 == nullptr || p.st == nullptr) return -12;
     if (p.K < 1 || p.Bl < 1 || d.B % p.Bl || p.row_ld < 2 * d.S + d.A + 3) return -13;
@@ -1292,6 +1293,14 @@ struct WgradGroup {
     int Bp;             // K: batch rows rounded up to a multiple of 32
     int pad_;
     WgradAdam opt;
+    // Prioritised replay: the batch of the NEXT update is drawn by extra workgroups of the finishing
+    // launch (one wave per row), where it sees the priorities this update has just written back (the
+    // tree update rides in the actor phase launch before) and costs nothing on the critical path; a
+    // sampling kernel at the start of every update is 6.8 us.  In device memory, not in the kernel
+    // arguments: the tree descent indexes the level arrays of the descriptor at run time.
+    const SampleArgs* smp;     // null: none
+    int smp_rows;              // = smp->B (host copy: smp points to device memory)
+    int pad2_;
 };
 
 // optimiser state of one parameter, fetched at kernel entry (ahead of the stash loads and the
@@ -1379,8 +1388,17 @@ __global__ __launch_bounds__(64 * NWV) void wgrad_kernel(const WgradGroup g) {
     float* cs = wg_smem + NWV * 16 * 64;       // [NWV][32] partial row sums
     const int total = g.total_tiles;
     const int id = blockIdx.x;
-    if (id >= total) {          // the extra workgroup of a finishing launch
+    if (id == total) {          // the extra workgroup of a finishing launch
         wgrad_finish_role<NWV>(g.opt, cs);
+        return;
+    }
+    if (id > total) {           // the batch of the next update (SampleArgs): one wave per row
+        const SampleArgs& sa = *g.smp;
+        const int b = (id - total - 1) * NWV + (int)(threadIdx.x >> 6);
+        const long long size = sa.st->replay_size;
+        // stream position of the next update = updates completed once this one is: step_cur (step_done
+        // is being advanced by the finish role of this very launch)
+        if (b < sa.B && size > 0) sample_row(sa, b, sa.st->step_cur, size, threadIdx.x & 63);
         return;
     }
     STAMP(1, 20);
@@ -1518,7 +1536,11 @@ static int launch_wgrad(K kernel, int nwv, int grid, const WgradGroup& g, hipStr
         hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return (int)e;
     }
-    const int extra = (g.opt.p != nullptr && g.opt.finish_step) ? 1 : 0;       // wgrad_finish_role
+    int extra = (g.opt.p != nullptr && g.opt.finish_step) ? 1 : 0;       // wgrad_finish_role
+    if (g.smp != nullptr) {
+        if (!extra || g.smp_rows < 1) return -5;          // only behind the finish workgroup
+        extra += (g.smp_rows + nwv - 1) / nwv;
+    }
     hipLaunchKernelGGL(kernel, dim3(grid + extra), dim3(64 * nwv), lds, stream, g);
     return (int)hipGetLastError();
 }

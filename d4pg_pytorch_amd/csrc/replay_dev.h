@@ -122,3 +122,101 @@ __device__ __forceinline__ void tree_update_body(const TreeUpdateArgs& a) {
         __syncthreads();
     }
 }
+
+// ---------------------------------------------------------------------------
+// Sampling: one wave draws one row.
+struct SampleArgs {
+    ReplayDesc rp;
+    TreeDesc t;
+    DevState* st;
+    float* sa;        // [B, ld_x]  cols [0,S) = state, [S,S+A) = action
+    float* s_pi;      // [B, ld_x]  cols [0,S) = state          (action columns are produced by the actor)
+    float* s2_a2;     // [B, ld_x]  cols [0,S) = next state     (action columns are produced by the target actor)
+    float* reward;    // [B]
+    float* done;      // [B]
+    float* gamma;     // [B]
+    float* weights;   // [B]
+    long long* idx;   // [B]
+    int B, ld_x;
+    int prioritized;
+    int do_tick;
+    float beta1, beta2;           // Adam betas for the tick
+    float per_b0, per_b1;         // importance-exponent schedule
+    long long total_steps;
+};
+
+// Draw the replay slot of sample `b` of `B` (all 64 lanes of the wave take part and get the
+// same result): uniform, or stratified proportional through the fan-out-64 tree with the
+// importance weight (p_min / p_leaf)^beta.  `step` selects the RNG stream position and the
+// point on the beta schedule.
+__device__ __forceinline__ long long draw_slot(const TreeDesc& t, int prioritized, int b, int B, long long step,
+                                               long long size, unsigned long long seed, float per_b0, float per_b1,
+                                               long long total_steps, int lane, float& w) {
+    uint32_t rnd[4];
+    philox4x32((uint32_t)b, (uint32_t)step, (uint32_t)(step >> 32), 0x5EEDu, (uint32_t)seed, (uint32_t)(seed >> 32),
+               rnd);
+    const double u = u01_from_bits(rnd[0], rnd[1]);
+    long long slot;
+    w = 1.f;
+    if (!prioritized) {
+        slot = (long long)(u * (double)size);
+        if (slot >= size) slot = size - 1;
+        return slot;
+    }
+    // root totals from the top level
+    const double top = tree_load_sum(t, t.L, lane);
+    const double total = wave_sum_d(top);
+    const float pmin = wave_min(tree_load_min(t, t.L, lane));
+    double target = ((double)b + u) * (total / (double)B);
+    long long g = 0;
+    float pleaf = 0.f;
+    for (int l = t.L; l >= 0; --l) {
+        const long long c = g * 64 + lane;
+        const double v = tree_load_sum(t, l, c);
+        const double incl = wave_scan_incl_d(v, lane);
+        const unsigned long long live = __ballot(v > 0.0);
+        const unsigned long long hit = __ballot(v > 0.0 && incl > target);
+        int pick;
+        if (hit) pick = __ffsll((long long)hit) - 1;
+        else if (live) pick = 63 - __clzll((long long)live);   // rounding pushed target past the end
+        else pick = 0;
+        const double excl = __shfl(incl - v, pick, 64);
+        target -= excl;
+        if (target < 0.0) target = 0.0;
+        g = g * 64 + pick;
+        if (l == 0) pleaf = (float)__shfl(v, pick, 64);
+    }
+    slot = g < size ? g : size - 1;
+    // beta schedule evaluated locally (per_beta in DevState belongs to the tick)
+    double frac = (double)step / (double)(total_steps > 0 ? total_steps : 1);
+    frac = frac > 1.0 ? 1.0 : frac;
+    const float beta = (float)(per_b0 + frac * (per_b1 - per_b0));
+    w = (pleaf > 0.f && pmin < INFINITY) ? powf(pmin / pleaf, beta) : 1.f;
+    return slot;
+}
+
+
+// Draw sample `b` of the batch consumed by the update at stream position `step` and gather its row
+// into the learner's input buffers (all 64 lanes of one wave).
+__device__ __forceinline__ void sample_row(const SampleArgs& a, int b, long long step, long long size, int lane) {
+    float w;
+    const long long slot = draw_slot(a.t, a.prioritized, b, a.B, step, size, a.st->seed, a.per_b0, a.per_b1,
+                                     a.total_steps, lane, w);
+    const float* row = a.rp.rows + slot * a.rp.row_ld;
+    const int S = a.rp.S, A = a.rp.A;
+    const size_t ob = (size_t)b * a.ld_x;
+    for (int c = lane; c < S; c += 64) {
+        const float s = row[c];
+        a.sa[ob + c] = s;
+        a.s_pi[ob + c] = s;
+        a.s2_a2[ob + c] = row[S + A + 3 + c];
+    }
+    for (int c = lane; c < A; c += 64) a.sa[ob + S + c] = row[S + c];
+    if (lane == 0) {
+        a.reward[b] = row[S + A];
+        a.done[b] = row[S + A + 1];
+        a.gamma[b] = row[S + A + 2];
+        a.weights[b] = w;
+        a.idx[b] = slot;
+    }
+}

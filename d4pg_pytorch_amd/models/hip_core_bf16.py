@@ -115,6 +115,26 @@ class HipCoreBf16(HipCore):
     def attach_replay(self, replay) -> None:
         super().attach_replay(replay)
         self._ahead = None
+        self._presampled_step = -1
+        self._smp_dev = None
+        if replay is not None and replay.prioritized:
+            # descriptor of "sample the next batch into the input buffers", in device memory for the
+            # sampling role of the finishing weight-gradient launch (WgradGroup::smp)
+            raw = bytes(replay.sample_args(self, do_tick=False))
+            self._smp_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+        self._graphs = {k: v for k, v in self._graphs.items() if not k.startswith("replay")}
+        self._segments_cache = {k: v for k, v in self._segments_cache.items() if not k.startswith("replay")}
+
+    def _per_sampling_rides_along(self) -> bool:
+        """Prioritised replay without gradient exchange: every update draws the batch of the NEXT one in
+        extra workgroups of its last launch (after its priorities are written back), instead of a
+        sampling kernel at the start of every update."""
+        return (self.replay is not None and self.replay.prioritized and self.grad_sync is None
+                and getattr(self, "_smp_dev", None) is not None and bool(int(os.environ.get("D4PG_PER_SAMPLE_ROLE", "1"))))
+
+    def _write_dev_state(self, *args, **kw) -> None:
+        super()._write_dev_state(*args, **kw)
+        self._presampled_step = -1          # step counter / RNG stream changed: the batch in the input buffers is void
 
     def update_from_replay(self) -> torch.Tensor:
         """With uniform replay the batches of the next ``sample_ahead`` updates are drawn by ONE
@@ -131,6 +151,18 @@ class HipCoreBf16(HipCore):
                                                int(self.cfg.get("sample_ahead", 8)), reseed=False)
         if ahead is not None and self.grad_sync is None:
             return ahead.update()
+        if self._per_sampling_rides_along():
+            if self.use_graph and "replay" not in self._graphs:
+                # the warm-up run of the capture works on (and overwrites) the input buffers
+                self.replay.enqueue_sample(self, do_tick=False)
+                self._graphs["replay"] = self._capture(self._segments("replay"), fused=True, reps=1)
+                self._presampled_step = -1
+            if self._presampled_step != self.step:        # first update, or the state was reset / reloaded
+                self.replay.enqueue_sample(self, do_tick=False)
+            self._run("replay")
+            self.step += 1
+            self._presampled_step = self.step
+            return self.prio
         return super().update_from_replay()
 
     def update_from_replay_many(self, n: int) -> int:
@@ -160,6 +192,7 @@ class HipCoreBf16(HipCore):
 
     def _restore(self, snap) -> None:
         super()._restore(snap)
+        self._presampled_step = -1
         self.refresh_shadows()
 
     def _phase_dims(self) -> H.PhaseDims:
@@ -195,7 +228,7 @@ class HipCoreBf16(HipCore):
             L.ks, L.ntiles, L.N = sh.b_ld // 32, sh.b_rows // 16, sh.b_c1 - sh.b_c0
         return L
 
-    def _wgrad(self, triples, opt=None) -> None:
+    def _wgrad(self, triples, opt=None, sample_next: bool = False) -> None:
         """dW/db of up to three layers in one launch.  ``opt=(lr, finish)`` additionally applies
         Adam + Polyak + the shadow refresh inside the same kernel (no data parallelism only)."""
         g = H.WgradGroup()
@@ -221,6 +254,8 @@ class HipCoreBf16(HipCore):
             o.B, o.inv_B = self.B, 1.0 / self.B
             o.lr, o.beta1, o.beta2, o.eps, o.tau = lr, self.betas[0], self.betas[1], self.eps, self.tau
             o.finish_step = 1 if finish else 0
+        if sample_next:
+            g.smp, g.smp_rows = self._smp_dev.data_ptr(), self.B
         H._check(H.lib().d4pg_wgrad(g, H.stream_ptr()), "d4pg_wgrad")
 
     def _segments(self, source: str):
@@ -267,8 +302,10 @@ class HipCoreBf16(HipCore):
             a.sh = self._shadow_args(net, slots, net.base)
             return a
 
+        per_role = source == "replay" and fuse_opt and self._per_sampling_rides_along()
+
         def seg_critic() -> None:
-            if source == "replay":
+            if source == "replay" and not per_role:
                 self.replay.enqueue_sample(self, do_tick=True)
             elif source == "external":
                 H._check(H.lib().d4pg_tick(st, b1, b2, cfg["priority_beta_start"], cfg["priority_beta_end"],
@@ -279,6 +316,12 @@ class HipCoreBf16(HipCore):
             a.d = dims
             if source in self.packed_direct:        # rows are read in place; the kernel ticks
                 a.pk = self.packed_direct[source]
+            elif per_role:                          # the batch was drawn by the previous update: only the tick is left
+                pk = a.pk
+                pk.enabled, pk.do_tick, pk.st = 0, 1, st
+                pk.beta1, pk.beta2 = b1, b2
+                pk.per_b0, pk.per_b1 = float(cfg["priority_beta_start"]), float(cfg["priority_beta_end"])
+                pk.total_steps = int(cfg["num_steps_train"])
             a.sa, a.s2 = self.sa.data_ptr(), self.s2a2.data_ptr()
             a.reward, a.done, a.gamma = self.reward.data_ptr(), self.done.data_ptr(), self.gamma.data_ptr()
             a.weights = self.weights.data_ptr()
@@ -337,7 +380,7 @@ class HipCoreBf16(HipCore):
             H._check(H.lib().d4pg_actor_phase(a, self.mt, H.stream_ptr()), "d4pg_actor_phase")
             self._wgrad([(self.a_daT, self.a_h2T, al[2], sl.actor[2]), (self.a_dh2T, self.a_h1T, al[1], sl.actor[1]),
                          (self.a_dh1T, self.sT, al[0], sl.actor[0])],
-                        opt=(self.lr_actor, True) if fuse_opt else None)
+                        opt=(self.lr_actor, True) if fuse_opt else None, sample_next=per_role)
 
         def seg_finish() -> None:
             if not fuse_opt:

@@ -148,6 +148,10 @@ class HbmReplay:
     # ------------------------------------------------------------------ sample
     def enqueue_sample(self, core, do_tick: bool = True, stream=None) -> None:
         """Sample ``core.B`` rows into the core's static input buffers (enqueue only)."""
+        H.launch("d4pg_replay_sample", self.sample_args(core, do_tick), stream)
+
+    def sample_args(self, core, do_tick: bool = True) -> H.SampleArgs:
+        """Launch descriptor of :meth:`enqueue_sample`."""
         cfg = self.cfg
         a = H.SampleArgs()
         a.rp, a.t, a.st = self._replay_desc(), self._tree_desc(), self.dev_state.data_ptr()
@@ -160,7 +164,7 @@ class HbmReplay:
         a.beta1, a.beta2 = float(cfg["adam_beta1"]), float(cfg["adam_beta2"])
         a.per_b0, a.per_b1 = float(cfg["priority_beta_start"]), float(cfg["priority_beta_end"])
         a.total_steps = int(cfg["num_steps_train"])
-        H.launch("d4pg_replay_sample", a, stream)
+        return a
 
     def packed_width(self) -> int:
         """Floats per row of a packed batch: the replay row, the importance weight and the slot."""

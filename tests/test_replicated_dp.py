@@ -190,3 +190,33 @@ def test_critic_forward_made_ahead_is_tagged_and_dropped_when_weights_change(mon
         outs[mode] = (core.online.flat.clone(), core.target.flat.clone(), core.adam_v.clone())
     for a, b in zip(outs["ahead"], outs["inline"]):
         assert torch.equal(a, b)
+
+
+def test_prioritised_batch_drawn_by_the_previous_update_equals_the_sampling_kernel(monkeypatch):
+    """Prioritised replay, bf16 pipeline: the batch of update u + 1 is drawn in extra workgroups of the
+    last launch of update u (after its priority write-back).  Same RNG stream positions and the same tree
+    state as a sampling kernel at the start of update u + 1, hence bit-identical parameters and priorities -
+    also across a reload of the state in between."""
+    from d4pg_pytorch_amd.models.core import build_core
+    from d4pg_pytorch_amd.replay.hbm_replay import HbmReplay
+    outs = {}
+    for mode in ("role", "kernel"):
+        monkeypatch.setenv("D4PG_PER_SAMPLE_ROLE", "1" if mode == "role" else "0")
+        cfg = _cfg(256, per=1)
+        core = build_core(cfg, "cuda")
+        rp = HbmReplay(cfg, "cuda", core.dev_state)
+        rp.insert(_rows(rp, 20_000, 5))
+        core.attach_replay(rp)
+        assert core._per_sampling_rides_along() == (mode == "role")
+        for _ in range(6):
+            core.update_from_replay()
+        bundle = core.state_bundle()
+        core.load_state_bundle(bundle)             # voids the batch waiting in the input buffers
+        rp.insert(_rows(rp, 3_000, 6))             # new rows at the running max priority
+        for _ in range(5):
+            core.update_from_replay()
+        torch.cuda.synchronize()
+        assert core.read_dev_state().step_done == 11
+        outs[mode] = (core.online.flat.clone(), core.target.flat.clone(), rp.leaf.clone(), core.idx.clone())
+    for a, b in zip(outs["role"][:3], outs["kernel"][:3]):
+        assert torch.equal(a, b)
