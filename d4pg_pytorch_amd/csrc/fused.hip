@@ -382,8 +382,18 @@ __device__ __forceinline__ RowSrc plain_src(const float* base, long long stride,
 // delta = 1: the batch of the NEXT update
 __device__ __forceinline__ RowSrc packed_src(const PackedIn& p, int col0, int delta = 0) {
     const long long s = p.st->step_done - p.step0 + delta;
-    const int j = (int)(s % p.K);
-    const float* chunk = ((s / p.K) & 1) ? p.in1 : p.in0;
+    // 32-bit division while the count fits (a 64-bit one is a ~150-instruction routine at the head of
+    // the dependent chain of every phase kernel)
+    int j, odd;
+    if (((unsigned long long)s >> 32) == 0) {
+        const unsigned q = (unsigned)s / (unsigned)p.K;
+        j = (int)((unsigned)s - q * (unsigned)p.K);
+        odd = (int)(q & 1u);
+    } else {
+        j = (int)(s % p.K);
+        odd = (int)((s / p.K) & 1);
+    }
+    const float* chunk = odd ? p.in1 : p.in0;
     const long long ldp = p.row_ld + 4;
     return RowSrc{chunk + (long long)j * p.Bl * ldp + col0, ldp, (long long)p.K * p.Bl * ldp, p.Bl};
 }
