@@ -95,7 +95,10 @@ EXTENSION_DEFAULTS: Dict[str, Any] = {
     "max_env_steps_per_agent": 1_000_000,  # agent.py:60 bound, kept as a safety stop
     "updates_per_env_step": None,    # optional throttle: learner waits so updates <= ratio * env_steps
     # --- MI355X execution ---
-    "compute_dtype": "fp32",         # "fp32" (f32 MFMA, bit-faithful) | "bf16" (bf16 MFMA, fp32 master weights)
+    "compute_dtype": "auto",         # GPU learner: "bf16" (fused row-local pipeline: bf16 MFMA operands, fp32 master
+                                     # weights / Adam / logits / loss; 3x the update rate) | "fp32" (exact f32 MFMA
+                                     # kernels, tracks eager PyTorch to 2e-5) | "auto": bf16 where its shape limits
+                                     # (batch a multiple of 16, hidden layers that fit the LDS) hold, else fp32
     "use_hip_graph": True,           # replay the whole update as one captured HIP graph
     "fused_learner": "auto",         # "auto": HIP kernels on cuda, torch ops on cpu; "torch": force eager torch
     "metrics_interval": 100,         # device-side metric accumulator is read back every N updates
@@ -257,7 +260,7 @@ def finalize_config(raw: Dict[str, Any]) -> Dict[str, Any]:
     need(cfg["dp_mode"] in ("replicated", "grad_allreduce"), "dp_mode must be 'replicated' or 'grad_allreduce'")
     need(cfg["envs_per_agent"] >= 1, "envs_per_agent must be >= 1")
     need(cfg["critic_loss"] in ("bce", "ce"), "critic_loss must be 'bce' or 'ce'")
-    need(cfg["compute_dtype"] in ("fp32", "bf16"), "compute_dtype must be 'fp32' or 'bf16'")
+    need(cfg["compute_dtype"] in ("auto", "fp32", "bf16"), "compute_dtype must be 'auto', 'fp32' or 'bf16'")
     need(cfg["replay_device"] in ("auto", "hbm", "host"), "replay_device must be auto|hbm|host")
     need(cfg["log_backend"] in ("tb", "jsonl", "both"), "log_backend must be tb|jsonl|both")
     if model == "d4pg":

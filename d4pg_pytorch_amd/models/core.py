@@ -233,9 +233,14 @@ def build_core(cfg: Dict, device=None, seed: Optional[int] = None) -> CoreBase:
     device = torch.device(device if device is not None else cfg["device"])
     want = cfg.get("fused_learner", "auto")
     if device.type == "cuda" and want != "torch":
-        if cfg.get("compute_dtype", "fp32") == "bf16":
+        dtype = cfg.get("compute_dtype", "auto")
+        if dtype in ("bf16", "auto"):
             from .hip_core_bf16 import HipCoreBf16
-            return HipCoreBf16(cfg, device, seed)
+            try:
+                return HipCoreBf16(cfg, device, seed)
+            except ValueError:            # shape outside the fused pipeline's limits (batch % 16, LDS per workgroup)
+                if dtype == "bf16":
+                    raise
         from .hip_core import HipCore
         return HipCore(cfg, device, seed)
     return TorchCore(cfg, device, seed)

@@ -126,3 +126,17 @@ def test_bf16_update_from_replay_and_resume(per, tmp_path):
     core.update(b)
     other.update(b)
     torch.testing.assert_close(other.online.flat, core.online.flat, rtol=0, atol=0)
+
+
+def test_compute_dtype_auto_picks_the_fused_pipeline_where_it_fits():
+    """``compute_dtype: auto`` (the default): the bf16 pipeline when the batch is a multiple of 16,
+    the exact fp32 kernels otherwise; an explicit ``bf16`` with such a batch is an error."""
+    from d4pg_pytorch_amd.models.core import build_core
+    from d4pg_pytorch_amd.models.hip_core import HipCore
+    from d4pg_pytorch_amd.models.hip_core_bf16 import HipCoreBf16
+    assert default_config(env="Pendulum-v0")["compute_dtype"] == "auto"
+    assert isinstance(build_core(_cfg("d4pg", compute_dtype="auto"), "cuda"), HipCoreBf16)
+    odd = build_core(_cfg("d4pg", compute_dtype="auto", batch_size=40), "cuda")
+    assert isinstance(odd, HipCore) and not isinstance(odd, HipCoreBf16)
+    with pytest.raises(ValueError):
+        build_core(_cfg("d4pg", compute_dtype="bf16", batch_size=40), "cuda")
