@@ -26,8 +26,10 @@ Data-parallel modes (``--dp-mode``, N > 1):
                   latency-bound gradient all-reduces on the critical path.
   grad_allreduce  every rank runs the update on its 256 rows and the critic and actor
                   gradient buckets (0.7-0.9 MB each) are all-reduced before each Adam step.
-  both (default)  times the two back to back; ``value`` is the replicated mode, the other
-                  is reported as ``grad_allreduce_value``.
+  both (default)  times the two back to back; ``value`` is the mode the framework itself picks
+                  (``dp_mode: auto``: replicated up to a global batch of 2048 rows, which covers batch
+                  256 on 8 GPUs; gradient all-reduce beyond), the other one is reported as
+                  ``grad_allreduce_value`` / ``replicated_value``.
 Both make the update a single learner would make on the concatenated global batch.
 For N > 1 every rank also times the SAME configuration on its own GPU alone (no
 collectives, batch 256): ``single_gpu_same_config_value`` is what the N-GPU ``value`` should
@@ -108,7 +110,7 @@ def main() -> None:
         sys.exit(subprocess.call(cmd))
 
     from d4pg_pytorch_amd.config import default_config
-    from d4pg_pytorch_amd.parallel.comm import LocalComm, TorchDistComm, attach_data_parallel
+    from d4pg_pytorch_amd.parallel.comm import LocalComm, TorchDistComm, attach_data_parallel, resolve_dp_mode
 
     # one GPU per rank; ranks wrap around only when a multi-rank job is rehearsed on fewer GPUs
     # (D4PG_DIST_BACKEND=gloo, see parallel/comm.py)
@@ -218,20 +220,22 @@ def main() -> None:
             torch.cuda.empty_cache()
         if world == 1 and not args.dp_selftest:
             core, dt = run_grad_allreduce()
-        elif args.dp_mode == "grad_allreduce":
-            dp_mode = "grad_allreduce"
-            core, dt = run_grad_allreduce()
+        elif args.dp_mode != "both":
+            dp_mode = args.dp_mode
+            core, dt = run_replicated() if dp_mode == "replicated" else run_grad_allreduce()
         else:
-            dp_mode = "replicated"
-            if args.dp_mode == "both":
-                try:
-                    _, dt_ar = run_grad_allreduce()
-                    extra["grad_allreduce_value"] = round(args.steps / dt_ar * world, 2)
-                    extra["grad_allreduce_ms_per_step"] = round(1000.0 * dt_ar / args.steps, 5)
-                except Exception as exc:      # the headline mode must still be measured
-                    extra["grad_allreduce_error"] = repr(exc)[:200]
-                torch.cuda.empty_cache()
-            core, dt = run_replicated()
+            # both, the one the framework would pick (dp_mode: auto) last: it is the headline `value`
+            dp_mode = resolve_dp_mode("auto", args.batch, world)
+            other, run_other = (("grad_allreduce", run_grad_allreduce) if dp_mode == "replicated"
+                                else ("replicated", run_replicated))
+            try:
+                _, dt_o = run_other()
+                extra[other + "_value"] = round(args.steps / dt_o * world, 2)
+                extra[other + "_ms_per_step"] = round(1000.0 * dt_o / args.steps, 5)
+            except Exception as exc:      # the headline mode must still be measured
+                extra[other + "_error"] = repr(exc)[:200]
+            torch.cuda.empty_cache()
+            core, dt = run_replicated() if dp_mode == "replicated" else run_grad_allreduce()
 
     metrics = core.read_metrics()
     finite = all(map(lambda v: v == v and abs(v) != float("inf"), (metrics["value_loss"], metrics["policy_loss"])))

@@ -84,8 +84,9 @@ EXTENSION_DEFAULTS: Dict[str, Any] = {
     # --- topology ---
     "num_learners": 1,               # data-parallel learner ranks (one per GPU, RCCL)
     "learner_devices": None,         # list of device indices; default range(num_learners)
-    "dp_mode": "replicated",         # num_learners > 1: "replicated" (all-gather the sampled rows, every rank runs the
+    "dp_mode": "auto",               # num_learners > 1: "replicated" (all-gather the sampled rows, every rank runs the
                                      # update on the global batch) | "grad_allreduce" (all-reduce both gradient buckets)
+                                     # | "auto": replicated up to a global batch of 2048 rows, else grad_allreduce
     "exploiter_device": None,        # default: same as ``device``
     "envs_per_agent": 1,             # vectorised environments per explorer/exploiter process
     "replay_device": "auto",         # "hbm" (inside the learner, on its GPU) | "host" (sampler process) | "auto"
@@ -257,7 +258,8 @@ def finalize_config(raw: Dict[str, Any]) -> Dict[str, Any]:
          "replay_mem_size must be positive")
     need(cfg["action_high"] > cfg["action_low"], "action_high must exceed action_low")
     need(cfg["num_learners"] >= 1, "num_learners must be >= 1")
-    need(cfg["dp_mode"] in ("replicated", "grad_allreduce"), "dp_mode must be 'replicated' or 'grad_allreduce'")
+    need(cfg["dp_mode"] in ("auto", "replicated", "grad_allreduce"),
+         "dp_mode must be 'auto', 'replicated' or 'grad_allreduce'")
     need(cfg["envs_per_agent"] >= 1, "envs_per_agent must be >= 1")
     need(cfg["critic_loss"] in ("bce", "ce"), "critic_loss must be 'bce' or 'ce'")
     need(cfg["compute_dtype"] in ("auto", "fp32", "bf16"), "compute_dtype must be 'auto', 'fp32' or 'bf16'")

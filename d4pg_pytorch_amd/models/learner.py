@@ -29,7 +29,7 @@ from typing import Dict, List, Optional
 import numpy as np
 import torch
 
-from ..parallel.comm import Comm, LocalComm, attach_data_parallel
+from ..parallel.comm import Comm, LocalComm, attach_data_parallel, resolve_dp_mode
 from ..parallel.ipc import ControlBlock, ShmRing, WeightSlab
 from ..utils.checkpoint import load_learner_bundle, save_learner_bundle
 from ..utils.logger import Logger
@@ -94,7 +94,8 @@ class Learner:
         self.log_dir = log_dir
         self.num_train_steps = int(config["num_steps_train"])
         # replicated data parallelism: every rank runs the update on the global batch
-        self.replicated = (self.comm.world > 1 and config.get("dp_mode", "replicated") == "replicated"
+        dp_mode = resolve_dp_mode(config.get("dp_mode", "auto"), int(config["batch_size"]), self.comm.world)
+        self.replicated = (self.comm.world > 1 and dp_mode == "replicated"
                            and self.device.type == "cuda" and config.get("fused_learner", "auto") != "torch")
         core_cfg = dict(config, batch_size=int(config["batch_size"]) * self.comm.world) if self.replicated else config
         self.core = build_core(core_cfg, self.device, seed=config["random_seed"])

@@ -176,6 +176,20 @@ class TorchDistComm(Comm):
             self._owns = False
 
 
+#: Largest global batch for which ``dp_mode: auto`` replicates the update.  One update costs 55 us at
+#: 256 rows and 66 us at 2048 (the phase kernels leave most of the chip idle and take the same time),
+#: but from there on it grows with the rows (92 us at 4096): past this point two gradient all-reduces
+#: of 0.7-0.9 MB are cheaper than redoing every other rank's rows.
+REPLICATED_MAX_GLOBAL_BATCH = 2048
+
+
+def resolve_dp_mode(mode: str, local_batch: int, world: int) -> str:
+    """``auto`` -> ``replicated`` while the global batch is small enough, else ``grad_allreduce``."""
+    if mode != "auto":
+        return mode
+    return "replicated" if int(local_batch) * int(world) <= REPLICATED_MAX_GLOBAL_BATCH else "grad_allreduce"
+
+
 def attach_data_parallel(core, comm: Comm) -> None:
     """Make ``core`` a data-parallel replica: identical start, summed gradients.
 

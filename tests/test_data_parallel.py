@@ -100,3 +100,15 @@ def test_two_gloo_processes_stay_bit_identical(tmp_path):
     for i in range(3):
         single.update(_batch(32, 10 + i))
     torch.testing.assert_close(a["online"], single.online.flat.detach(), rtol=0, atol=2e-6)
+
+
+def test_dp_mode_auto_replicates_only_small_global_batches():
+    from d4pg_pytorch_amd.config import default_config
+    from d4pg_pytorch_amd.parallel.comm import REPLICATED_MAX_GLOBAL_BATCH, resolve_dp_mode
+    assert default_config(env="Pendulum-v0")["dp_mode"] == "auto"
+    assert REPLICATED_MAX_GLOBAL_BATCH == 2048
+    assert resolve_dp_mode("auto", 256, 8) == "replicated"
+    assert resolve_dp_mode("auto", 4096, 8) == "grad_allreduce"
+    assert resolve_dp_mode("auto", 4096, 1) == "grad_allreduce"      # irrelevant for one rank, but well defined
+    assert resolve_dp_mode("grad_allreduce", 256, 2) == "grad_allreduce"
+    assert resolve_dp_mode("replicated", 4096, 8) == "replicated"
