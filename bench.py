@@ -49,7 +49,12 @@ import os
 import sys
 import time
 
-import torch
+# RCCL shares device buffers between the ranks' processes through dmabuf IPC handles; the legacy IPC
+# mode fails with "hipIpcGetMemHandle: invalid argument" on hosts whose driver only offers dmabuf.
+# Must be in the environment before the HIP runtime starts.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
