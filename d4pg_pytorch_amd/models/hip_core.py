@@ -341,6 +341,15 @@ class HipCore(CoreBase):
             sync(self.grad[lay.actor.base: lay.actor.base + lay.actor.numel])
             graphs[2].replay()
 
+    def ensure_captured(self, source: str, reps: int = 1) -> None:
+        """Capture the graph ``_run(source, reps)`` would replay, if it does not exist yet."""
+        sync = self.grad_sync
+        if not self.use_graph or (reps > 1 and sync is not None):
+            return
+        key = source + ("/dp" if sync is not None else "") + (f"/x{reps}" if reps > 1 else "")
+        if key not in self._graphs:
+            self._graphs[key] = self._capture(self._segments(source), fused=sync is None, reps=reps)
+
     def _capture(self, segs, fused: bool, reps: int = 1):
         """Warm up once eagerly (module loading, allocator) on a side stream,
         restore the state it touched, then capture."""

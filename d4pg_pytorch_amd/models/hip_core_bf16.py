@@ -193,6 +193,10 @@ class HipCoreBf16(HipCore):
     def _restore(self, snap) -> None:
         super()._restore(snap)
         self._presampled_step = -1
+        # the run that is being undone may have overwritten the tiles of a critic forward pass made
+        # ahead, while the restored device state still carries the tag of the old ones
+        off = H.DevStateMirror.pad_.offset
+        self.dev_state[off:off + 16].zero_()
         self.refresh_shadows()
 
     def _phase_dims(self) -> H.PhaseDims:

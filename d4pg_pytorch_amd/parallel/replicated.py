@@ -67,6 +67,7 @@ class ReplicatedDP:
             core.attach_replay(replay)
         self.step0 = int(core.step)
         self.n = 0                   # updates made through this driver
+        self._precaptured = False
         self._sample_args = [replay.sample_rows_args(self.local[p], self.Bl, self.K) for p in range(2)]
         prio_args = None
         if replay.prioritized:       # the rank that owns a row writes its priority back
@@ -120,22 +121,50 @@ class ReplicatedDP:
         return prio
 
     def update_many(self, n: int) -> int:
-        """Up to ``n`` updates; returns how many were made.  At a chunk boundary with at least a
-        whole chunk to go, the K updates that consume the chunk are ONE graph replay."""
+        """Up to ``n`` updates; returns how many were made.  The updates are ONE graph replay of the
+        largest power-of-two run that fits both ``n`` and the rest of the current chunk (a whole chunk
+        when aligned), so that a caller who asks for an odd number of updates, or starts in the middle
+        of a chunk, still replays a few long graphs instead of one graph per update (a graph launch
+        leaves ~8 us of idle GPU).  The graphs (one per run length) are captured on first use."""
         K = self.K
-        if n < K or self.n % K != 0 or K == 1:
+        j, c = self.n % K, self.n // K
+        r = min(int(n), K - j)
+        if r < 2:
             self.update()
             return 1
-        core, c = self.core, self.n // K
-        if not (c == 0 and getattr(self, "_primed_by_inspection", False)):
-            if c == 0:
-                self._draw_chunk(0)
-            self._draw_chunk(c + 1)
-        if self.world > 1:
-            torch.cuda.current_stream(core.device).wait_event(self.ready[c & 1])
-        core.update_from_source("gathered", K)
-        self.n += K
-        return K
+        r = 1 << (r.bit_length() - 1)
+        if not self._precaptured:
+            self._precapture()
+        core = self.core
+        if j == 0:
+            if not (c == 0 and getattr(self, "_primed_by_inspection", False)):
+                if c == 0:
+                    self._draw_chunk(0)
+                self._draw_chunk(c + 1)
+            if self.world > 1:
+                torch.cuda.current_stream(core.device).wait_event(self.ready[c & 1])
+        core.update_from_source("gathered", r)
+        self.n += r
+        return r
+
+    def _precapture(self) -> None:
+        """Capture the graph of every run length now (each capture makes one throw-away update and
+        restores the state), so that none of them falls into a timed or latency-sensitive region."""
+        self._precaptured = True
+        core = self.core
+        if not getattr(core, "use_graph", False) or core.grad_sync is not None:
+            return
+        if self.n == 0 and not getattr(self, "_primed_by_inspection", False):
+            # the throw-away updates read chunk 0: draw it (and chunk 1, as update() would) first
+            self._draw_chunk(0)
+            self._draw_chunk(1)
+            self._primed_by_inspection = True
+            if self.world > 1:
+                torch.cuda.current_stream(core.device).wait_event(self.ready[0])
+        r = 1 << (self.K.bit_length() - 1)
+        while r >= 1:
+            core.ensure_captured("gathered", r)
+            r >>= 1
 
     def current_batch(self) -> torch.Tensor:
         """The packed global batch ``[world * Bl, W]`` the NEXT ``update()`` will consume (testing /

@@ -220,3 +220,37 @@ def test_prioritised_batch_drawn_by_the_previous_update_equals_the_sampling_kern
         outs[mode] = (core.online.flat.clone(), core.target.flat.clone(), rp.leaf.clone(), core.idx.clone())
     for a, b in zip(outs["role"][:3], outs["kernel"][:3]):
         assert torch.equal(a, b)
+
+
+def test_odd_update_counts_replay_power_of_two_runs_and_late_captures_drop_the_ahead_tiles():
+    """``update_many`` with counts that are not multiples of the chunk, starting in the middle of a chunk,
+    and a graph captured after real updates (whose warm-up run overwrites the critic tiles made ahead):
+    bit-identical to one update per call on the plain sampling path."""
+    from d4pg_pytorch_amd.models.core import build_core
+    from d4pg_pytorch_amd.replay.hbm_replay import HbmReplay
+    outs = {}
+    for mode in ("plain", "runs"):
+        cfg = dict(_cfg(256), sample_ahead=1 if mode == "plain" else 8)
+        core = build_core(cfg, "cuda")
+        rp = HbmReplay(cfg, "cuda", core.dev_state)
+        rp.insert(_rows(rp, 20_000, 9))
+        core.attach_replay(rp)
+        if mode == "plain":
+            for _ in range(37):
+                core.update_from_replay()
+        else:
+            for _ in range(3):                      # single-update graph first, tiles for update 4 waiting
+                core.update_from_replay()
+            made = []
+            for want in (13, 1, 20):                # captures the run graphs at step 3; 13 = 4 + 1 + 8, ...
+                done = 0
+                while done < want:
+                    k = core.update_from_replay_many(want - done)
+                    made.append(k)
+                    done += k
+                assert done == want
+            assert max(made) == 8 and sum(made) == 34 and len(made) < 12
+        torch.cuda.synchronize()
+        assert core.read_dev_state().step_done == 37
+        outs[mode] = (core.online.flat.clone(), core.target.flat.clone())
+    assert torch.equal(outs["plain"][0], outs["runs"][0]) and torch.equal(outs["plain"][1], outs["runs"][1])
