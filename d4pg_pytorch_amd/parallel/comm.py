@@ -200,7 +200,9 @@ def attach_data_parallel(core, comm: Comm) -> None:
       HIP core already scales its loss by 1/(world*B), so a plain sum is right;
       the torch core averages over its local batch, so the sum is divided by world.
     """
-    if comm.world == 1:
+    # D4PG_DP_SELFTEST=1: keep the gradient exchange (three graph segments, two all-reduces, separate
+    # optimiser kernels) over a world of one, to exercise and time that path on a single GPU
+    if comm.world == 1 and not (os.environ.get("D4PG_DP_SELFTEST") and isinstance(comm, TorchDistComm)):
         core.grad_sync = None
         return
     with torch.no_grad():
