@@ -27,8 +27,7 @@ Data-parallel modes (``--dp-mode``, N > 1):
   grad_allreduce  every rank runs the update on its 256 rows and the critic and actor
                   gradient buckets (0.7-0.9 MB each) are all-reduced before each Adam step.
   both (default)  times the two back to back; ``value`` is the mode the framework itself picks
-                  (``dp_mode: auto``: replicated up to a global batch of 2048 rows, which covers batch
-                  256 on 8 GPUs; gradient all-reduce beyond), the other one is reported as
+                  (``dp_mode: auto``: replicated up to a global batch of 8192 rows; gradient all-reduce beyond), the other one is reported as
                   ``grad_allreduce_value`` / ``replicated_value``.
 Both make the update a single learner would make on the concatenated global batch.
 For N > 1 every rank also times the SAME configuration on its own GPU alone (no

@@ -86,7 +86,7 @@ EXTENSION_DEFAULTS: Dict[str, Any] = {
     "learner_devices": None,         # list of device indices; default range(num_learners)
     "dp_mode": "auto",               # num_learners > 1: "replicated" (all-gather the sampled rows, every rank runs the
                                      # update on the global batch) | "grad_allreduce" (all-reduce both gradient buckets)
-                                     # | "auto": replicated up to a global batch of 2048 rows, else grad_allreduce
+                                     # | "auto": replicated up to a global batch of 8192 rows, else grad_allreduce
     "exploiter_device": None,        # default: same as ``device``
     "envs_per_agent": 1,             # vectorised environments per explorer/exploiter process
     "replay_device": "auto",         # "hbm" (inside the learner, on its GPU) | "host" (sampler process) | "auto"

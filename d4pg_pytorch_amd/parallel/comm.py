@@ -176,11 +176,12 @@ class TorchDistComm(Comm):
             self._owns = False
 
 
-#: Largest global batch for which ``dp_mode: auto`` replicates the update.  One update costs 55 us at
-#: 256 rows and 66 us at 2048 (the phase kernels leave most of the chip idle and take the same time),
-#: but from there on it grows with the rows (92 us at 4096): past this point two gradient all-reduces
-#: of 0.7-0.9 MB are cheaper than redoing every other rank's rows.
-REPLICATED_MAX_GLOBAL_BATCH = 2048
+#: Largest global batch for which ``dp_mode: auto`` replicates the update.  Measured on one MI355X, us per
+#: update: replicated, by global batch: 256: 55, 2048: 66, 4096: 92, 8192: 131; the gradient-exchange
+#: path (three graph segments, two all-reduces, separate optimiser kernels, per-update sampling kernel)
+#: over a world of one, by local batch: 256: 110, 4096: 161 - before any xGMI latency of the two
+#: 0.7-0.9 MB all-reduces.  Redoing the other ranks' rows is cheaper than that up to 8192 rows.
+REPLICATED_MAX_GLOBAL_BATCH = 8192
 
 
 def resolve_dp_mode(mode: str, local_batch: int, world: int) -> str:
