@@ -103,6 +103,8 @@ EXTENSION_DEFAULTS: Dict[str, Any] = {
     "use_hip_graph": True,           # replay the whole update as one captured HIP graph
     "fused_learner": "auto",         # "auto": HIP kernels on cuda, torch ops on cpu; "torch": force eager torch
     "metrics_interval": 100,         # device-side metric accumulator is read back every N updates
+    "control_interval": 1024,        # several learners: updates between two agreements on the stop flag (one 8-byte
+                                     # all-reduce; a rank must not leave the collectives of the others on its own)
     "ring_capacity": 4096,           # rows per explorer->replay shared-memory ring
     "ingest_chunk": 1024,            # rows per pinned H2D staging chunk
     "ingest_interval": 32,           # learner updates between two drains of the explorer rings
@@ -144,7 +146,7 @@ _INT_KEYS = {
     "max_ep_length", "replay_mem_size", "n_step_returns", "update_agent_ep", "replay_queue_size",
     "batch_queue_size", "replay_memory_prioritized", "num_episode_save", "save_buffer_on_disk",
     "dense_size", "num_atoms", "num_learners", "envs_per_agent", "weight_publish_interval",
-    "max_env_steps_per_agent", "metrics_interval", "ring_capacity", "ingest_chunk", "ingest_interval", "sample_ahead",
+    "max_env_steps_per_agent", "metrics_interval", "ring_capacity", "ingest_chunk", "ingest_interval", "sample_ahead", "control_interval",
     "ou_decay_period", "learner_checkpoint_interval",
 }
 _FLOAT_KEYS = {

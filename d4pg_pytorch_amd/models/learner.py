@@ -223,7 +223,11 @@ class Learner:
                     "data_struct/global_episode": float(ctrl.global_episode),
                     "data_struct/ring_dropped": float(sum(r.dropped for r in rings))}
 
-        while core.step < self.num_train_steps and not ctrl.stop:
+        # Several learners step in lockstep through their collectives: none may leave on its own.  The stop
+        # flag is therefore agreed on (max over ranks of a control scalar) every `control_interval` updates.
+        world = self.comm.world
+        control_every = max(1, int(cfg.get("control_interval", 1024)))
+        while core.step < self.num_train_steps and not (ctrl.stop and world == 1):
             if len(replay) < min_rows or self._throttle():
                 moved = ingest.poll()
                 if moved and dp is not None:
@@ -231,6 +235,8 @@ class Learner:
                 if moved == 0:
                     time.sleep(0.0005)
                 ctrl.heartbeat(0, int(time.time() * 1000))
+                if ctrl.stop:            # starved and told to stop: the job is being torn down
+                    break
                 continue
             prev = core.step
             if prev % ingest_every == 0 or prev // ingest_every != last_ingest // ingest_every:
@@ -239,6 +245,9 @@ class Learner:
                     dp.mark_inserted()
             burst(self.num_train_steps - prev)       # one update, or a whole drawn-ahead chunk as one graph
             self._after_update(extra, prev)
+            if world > 1 and prev // control_every != core.step // control_every:
+                if self.comm.all_reduce_max_scalar(1.0 if ctrl.stop else 0.0) > 0.0:
+                    break
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
         if dp is not None:
