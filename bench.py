@@ -10,7 +10,7 @@ backward/Adam, Polyak on both targets (and the priority write-back with --per).
 Nothing is skipped or cached; weights are random-init, the replay is filled
 with synthetic transitions of the environment's observation/action shape.
 
-Configurations (the ones BASELINE.json names):
+Configurations:
   N == 1 : LunarLanderContinuous-v2 D4PG, batch 256, n-step 5, 51 atoms, 400-wide MLPs
   N  > 1 : Walker2d-v2 D4PG, data-parallel learners over RCCL, batch 256 per rank (weak
            scaling: every rank draws 256 rows per update from its own HBM replay shard;
