@@ -116,6 +116,8 @@ EXTENSION_DEFAULTS: Dict[str, Any] = {
     "learner_checkpoint_interval": 0,  # 0 = only at the end
     "heartbeat_timeout_s": 120.0,
     "log_backend": "tb",             # "tb" (TensorBoard event files) | "jsonl" | "both"
+    "check_rings": False,            # race detection (train.py --check): every ring slot carries the running index of
+                                     # its row; the consumer verifies it, the run fails on a mismatch
     "synthetic_env": False,          # force the shape-only synthetic env even when the id is known
 }
 
@@ -158,7 +160,7 @@ _FLOAT_KEYS = {
 }
 _BOOL_KEYS = {
     "use_per_sample_gamma", "scale_action", "lossless_replay_queue", "use_hip_graph",
-    "synthetic_env",
+    "synthetic_env", "check_rings",
 }
 
 

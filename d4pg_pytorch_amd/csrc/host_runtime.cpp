@@ -84,11 +84,12 @@ struct alignas(64) RingHeader {
     uint64_t magic;
     uint64_t capacity;     // rows
     uint64_t row_floats;
-    uint64_t reserved;
+    uint64_t check;        // 1: every slot carries the index of the row it holds, verified on consumption
     alignas(64) std::atomic<uint64_t> write_idx;   // rows ever pushed   (producer-owned)
     alignas(64) std::atomic<uint64_t> read_idx;    // rows ever consumed (consumer-owned)
     alignas(64) std::atomic<uint64_t> dropped;     // rows refused because the ring was full
     std::atomic<uint64_t> closed;
+    std::atomic<uint64_t> seq_errors;              // check mode: consumed slots whose index was not the expected one
 };
 static_assert(sizeof(RingHeader) <= kHeaderBytes, "header too large");
 
@@ -96,7 +97,28 @@ struct Ring {
     Mapping map;
     RingHeader* hdr;
     float* data;
+    uint64_t* seq;         // [capacity] 1 + index of the row in the slot (behind the data area)
 };
+
+// Check mode (race detection): the producer stamps every slot with the running index of the row it
+// writes, the consumer verifies on consumption that slot (index % capacity) holds exactly row `index`:
+// a producer overrunning the consumer, a second producer or consumer, or a lost release/acquire pair
+// all show up as a mismatch.
+inline void ring_stamp(Ring* r, uint64_t first, uint64_t n) {
+    if (!r->hdr->check) return;
+    const uint64_t cap = r->hdr->capacity;
+    for (uint64_t i = 0; i < n; ++i) r->seq[(first + i) % cap] = first + i + 1;
+}
+inline void ring_verify(Ring* r, uint64_t first, uint64_t n) {
+    if (!r->hdr->check) return;
+    const uint64_t cap = r->hdr->capacity;
+    uint64_t bad = 0;
+    for (uint64_t i = 0; i < n; ++i) bad += r->seq[(first + i) % cap] != first + i + 1;
+    if (bad) r->hdr->seq_errors.fetch_add(bad);
+}
+inline uint64_t* ring_seq_ptr(void* base, uint64_t capacity, uint64_t row_floats) {
+    return reinterpret_cast<uint64_t*>((char*)base + kHeaderBytes + (size_t)capacity * row_floats * sizeof(float));
+}
 
 // ------------------------------------------------------------------ slab
 struct alignas(64) SlabHeader {
@@ -175,19 +197,22 @@ inline int pad4(int v) { return (v + 3) / 4 * 4; }
 // =============================================================================== ring API
 API void* ring_create(const char* name, uint64_t capacity, uint64_t row_floats) {
     if (capacity < 2 || row_floats < 1) return nullptr;
-    const size_t bytes = kHeaderBytes + (size_t)capacity * row_floats * sizeof(float);
+    const size_t bytes = kHeaderBytes + (size_t)capacity * row_floats * sizeof(float) + (size_t)capacity * sizeof(uint64_t);
     Mapping m = map_shm(name, bytes, true);
     if (!m.base) return nullptr;
     auto* hdr = new (m.base) RingHeader();
     hdr->capacity = capacity;
     hdr->row_floats = row_floats;
+    hdr->check = 0;
+    hdr->seq_errors.store(0);
     hdr->write_idx.store(0);
     hdr->read_idx.store(0);
     hdr->dropped.store(0);
     hdr->closed.store(0);
     std::atomic_thread_fence(std::memory_order_release);
     hdr->magic = kRingMagic;
-    return new Ring{m, hdr, reinterpret_cast<float*>((char*)m.base + kHeaderBytes)};
+    return new Ring{m, hdr, reinterpret_cast<float*>((char*)m.base + kHeaderBytes),
+                    ring_seq_ptr(m.base, capacity, row_floats)};
 }
 
 API void* ring_attach(const char* name) {
@@ -198,8 +223,13 @@ API void* ring_attach(const char* name) {
         munmap(m.base, m.bytes);
         return nullptr;
     }
-    return new Ring{m, hdr, reinterpret_cast<float*>((char*)m.base + kHeaderBytes)};
+    return new Ring{m, hdr, reinterpret_cast<float*>((char*)m.base + kHeaderBytes),
+                    ring_seq_ptr(m.base, hdr->capacity, hdr->row_floats)};
 }
+
+// Check mode on / off (set by the creator before any row is pushed) and its error count.
+API void ring_set_check(void* h, int on) { static_cast<Ring*>(h)->hdr->check = on ? 1 : 0; }
+API uint64_t ring_seq_errors(void* h) { return static_cast<Ring*>(h)->hdr->seq_errors.load(); }
 
 API void ring_detach(void* h) {
     auto* r = static_cast<Ring*>(h);
@@ -252,6 +282,7 @@ API int64_t ring_push(void* h, const float* rows, int64_t n, int64_t timeout_ms)
         const uint64_t pos = w % cap;
         if (take > cap - pos) take = cap - pos;   // contiguous span
         std::memcpy(r->data + pos * rf, rows + (size_t)done * rf, (size_t)take * rf * sizeof(float));
+        ring_stamp(r, w, take);
         hd->write_idx.store(w + take, std::memory_order_release);
         done += (int64_t)take;
     }
@@ -273,6 +304,7 @@ API int64_t ring_pop(void* h, float* out, int64_t max_rows) {
         const uint64_t pos = rd % cap;
         if (take > cap - pos) take = cap - pos;
         std::memcpy(out + (size_t)done * rf, r->data + pos * rf, (size_t)take * rf * sizeof(float));
+        ring_verify(r, rd, take);
         hd->read_idx.store(rd + take, std::memory_order_release);
         done += (int64_t)take;
     }
@@ -296,6 +328,7 @@ API int64_t ring_peek(void* h, uint64_t* row_offset, int64_t max_rows) {
 
 API void ring_advance(void* h, int64_t rows) {
     auto* r = static_cast<Ring*>(h);
+    ring_verify(r, r->hdr->read_idx.load(std::memory_order_relaxed), (uint64_t)rows);
     r->hdr->read_idx.fetch_add((uint64_t)rows, std::memory_order_release);
 }
 

@@ -206,6 +206,8 @@ class Engine:
             rl = row_ld(cfg["state_dim"], cfg["action_dim"])
             for _ in range(world * n_explorers_per_rank):
                 r = ShmRing.create(int(cfg["ring_capacity"]), rl)
+                if cfg.get("check_rings"):       # race detection: slot sequence numbers, verified on consumption
+                    r.set_check(True)
                 rings.append(r)
                 names.append(r.name)
             ring_names = [r.name for r in rings]
@@ -243,6 +245,13 @@ class Engine:
             self.final_env_steps = ctrl.env_steps
             self.final_episodes = ctrl.global_episode
             failed = ctrl.load(ControlBlock.FAILED)
+            self.ring_seq_errors = sum(r.seq_errors for r in rings)
+            if cfg.get("check_rings"):
+                pushed = sum(r.pushed_total for r in rings)
+                print(f"[engine] ring check: {pushed} rows through {len(rings)} rings, "
+                      f"{self.ring_seq_errors} sequence errors", flush=True)
+                if self.ring_seq_errors:
+                    failed = failed or 1
             for q in (batch_queue, priority_queue):
                 if q is not None:
                     empty_torch_queue(q)

@@ -48,6 +48,7 @@ def host_lib() -> C.CDLL:
             "ring_pushed_total": (u64, [vp]), "ring_close": (None, [vp]), "ring_is_closed": (C.c_int, [vp]),
             "ring_push": (i64, [vp, vp, i64, i64]), "ring_pop": (i64, [vp, vp, i64]),
             "ring_peek": (i64, [vp, C.POINTER(u64), i64]), "ring_advance": (None, [vp, i64]),
+            "ring_set_check": (None, [vp, C.c_int]), "ring_seq_errors": (u64, [vp]),
             "slab_create": (vp, [C.c_char_p, u64]), "slab_attach": (vp, [C.c_char_p]),
             "slab_detach": (None, [vp]), "slab_data_ptr": (vp, [vp]), "slab_n_floats": (u64, [vp]),
             "slab_version": (u64, [vp]), "slab_step": (i64, [vp]), "slab_begin_write": (None, [vp]),
@@ -144,6 +145,15 @@ class ShmRing(_Shm):
     @property
     def pushed_total(self) -> int:
         return host_lib().ring_pushed_total(self._h)
+
+    def set_check(self, on: bool = True) -> None:
+        """Race detection: the producer stamps every slot with the running index of its row and the
+        consumer verifies it on consumption (``seq_errors``).  Set by the creator before any push."""
+        host_lib().ring_set_check(self._h, 1 if on else 0)
+
+    @property
+    def seq_errors(self) -> int:
+        return host_lib().ring_seq_errors(self._h)
 
     def mark_closed(self) -> None:
         host_lib().ring_close(self._h)

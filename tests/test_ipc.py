@@ -63,6 +63,37 @@ def test_ring_cross_process_lossless_backpressure():
         assert ring.dropped == 0 and ring.closed
 
 
+def test_ring_check_mode_counts_slots_that_do_not_hold_the_expected_row():
+    """Race detection: in check mode every slot carries the running index of its row.  A clean
+    producer / consumer pair (copying pop and zero-copy peek + advance, across the wrap-around) never
+    trips it; a consumer that is made to skip ahead does."""
+    ctx = mp.get_context("spawn")
+    with ShmRing.create(64, 6) as ring:
+        ring.set_check(True)
+        p = ctx.Process(target=_producer, args=(ring.name, 3000, 6))
+        p.start()
+        seen = 0
+        deadline = time.time() + 60
+        while seen < 3000 and time.time() < deadline:
+            if seen % 2:
+                seen += ring.pop(17).shape[0]
+            else:
+                _, n = ring.peek(9)
+                ring.advance(n)
+                seen += n
+        p.join(30)
+        assert p.exitcode == 0 and seen == 3000
+        assert ring.seq_errors == 0 and ring.dropped == 0
+        # a consumer releasing rows that were never produced reads slots with other rows' indices
+        ring.advance(5)
+        assert ring.seq_errors == 5
+    with ShmRing.create(8, 2) as plain:             # off by default: nothing is stamped or verified
+        plain.push(np.zeros((3, 2), np.float32))
+        plain.advance(3)
+        plain.advance(2)
+        assert plain.seq_errors == 0
+
+
 def test_attach_unknown_segment_fails_loudly():
     with pytest.raises(OSError):
         ShmRing.attach("/d4pg_no_such_ring")

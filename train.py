@@ -18,12 +18,14 @@ parser = argparse.ArgumentParser(description="Run training")
 parser.add_argument("--config", type=str, help="Path to the config file.")
 parser.add_argument("--set", nargs="*", default=[], metavar="KEY=VALUE",
                     help="override config entries, e.g. --set device=cpu num_steps_train=1000")
+parser.add_argument("--check", action="store_true",
+                    help="race detection: validate the sequence numbers of the transition rings (check_rings)")
 
 if __name__ == "__main__":
     args = vars(parser.parse_args())
     if not args["config"]:
         parser.error("--config is required")
-    config = read_config(args["config"], overrides=args["set"])
+    config = read_config(args["config"], overrides=args["set"] + (["check_rings=true"] if args["check"] else []))
     engine = load_engine(config)
     exp_dir = engine.train()
     print(f"results in {exp_dir}")
