@@ -143,13 +143,14 @@ class HipCoreBf16(HipCore):
         kernel.  Prioritised replay keeps the draw inside every update, so that it sees the
         priorities the previous update wrote."""
         ahead = getattr(self, "_ahead", None)
-        if ahead is None and self.replay is not None and not self.replay.prioritized and self.grad_sync is None \
+        # (also with a gradient exchange between the graph segments: the draws are local to the rank)
+        if ahead is None and self.replay is not None and not self.replay.prioritized \
                 and int(self.cfg.get("sample_ahead", 8)) > 1:
             from ..parallel.comm import LocalComm
             from ..parallel.replicated import ReplicatedDP
             ahead = self._ahead = ReplicatedDP(self, self.replay, LocalComm(), self.B,
                                                int(self.cfg.get("sample_ahead", 8)), reseed=False)
-        if ahead is not None and self.grad_sync is None:
+        if ahead is not None:
             return ahead.update()
         if self._per_sampling_rides_along():
             if self.use_graph and "replay" not in self._graphs:

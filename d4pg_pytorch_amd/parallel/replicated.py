@@ -62,7 +62,8 @@ class ReplicatedDP:
             st = core.read_dev_state()
             core._write_dev_state(step=core.step, seed=(st.seed + 0x9E3779B97F4A7C15 * (self.rank + 1)),
                                   keep_replay=True)
-        core.grad_sync = None
+        if self.world > 1:
+            core.grad_sync = None        # replicas exchange rows, not gradients
         if core.replay is not replay:
             core.attach_replay(replay)
         self.step0 = int(core.step)
