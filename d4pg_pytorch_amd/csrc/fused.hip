@@ -548,7 +548,7 @@ __device__ __forceinline__ void critic_rows(const CriticPhaseArgs& a, int row0, 
         if (d.distributional) {
             float lt[SL], lo[SL], m[SL], dl[SL];
             // consecutive rows of a wave alternate between two scratch rows so that they can overlap
-            float* scratch = ((((r - wave) / NW) & 1) ? sb : sp) + wave * 256;
+            float* scratch = ((((r - wave) / NW) & 1) ? sb : sp) + wave * ((d.NO + 63) & ~63);
 #pragma unroll
             for (int s = 0; s < SL; ++s) {
                 const int j = lane + 64 * s;
@@ -728,8 +728,8 @@ __global__ __launch_bounds__(64 * NW) void critic_phase_kernel(const CriticPhase
     __bf16* dlg = (__bf16*)carve(M * d.ldd * 2);
     float* lg_t = (float*)carve(M * d.nop * 4);
     float* lg_o = (float*)carve(M * d.nop * 4);
-    float* sp = (float*)carve(NW * 256 * 4);
-    float* sb = (float*)carve(NW * 256 * 4);
+    float* sp = (float*)carve(NW * ((d.NO + 63) & ~63) * 4);      // per-wave projection rows (two sets)
+    float* sb = (float*)carve(NW * ((d.NO + 63) & ~63) * 4);
     float* rs = (float*)carve(4 * M * 4);           // reward | 1 - done | gamma | weight / B
     // per-row scalars of the loss: fetched now (registers), parked in LDS behind the inputs
     const int SA = d.S + d.A;
@@ -1100,7 +1100,7 @@ __global__ __launch_bounds__(64 * NW) void actor_phase_kernel(const ActorPhaseAr
 static int phase_lds_bytes_critic(const PhaseDims& d, int M, int nw) {
     auto al = [](int b) { return (b + 15) & ~15; };
     return 2 * al(M * d.ldx * 2) + 4 * al(M * d.ldh * 2) + al(M * d.ldd * 2) + 2 * al(M * d.nop * 4) +
-           2 * al(nw * 256 * 4) + al(4 * M * 4);
+           2 * al(nw * ((d.NO + 63) & ~63) * 4) + al(4 * M * 4);
 }
 static int phase_lds_bytes_actor(const PhaseDims& d, int M, int) {
     auto al = [](int b) { return (b + 15) & ~15; };
