@@ -61,6 +61,7 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(objdir, exist_ok=True)
     objs = []
     hipcc = _hipcc()
+    jobs = []
     for s in srcs:
         o = os.path.join(objdir, os.path.basename(s) + ".o")
         if force or _stale(o, [s] + headers):
@@ -69,8 +70,13 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
                 cmd.insert(1, "-DD4PG_STAMPS")
             if verbose:
                 print(" ".join(cmd), flush=True)
-            _run(cmd)
+            jobs.append(cmd)
         objs.append(o)
+    if jobs:        # the translation units are independent: compile them side by side
+        from concurrent.futures import ThreadPoolExecutor
+        workers = max(1, min(len(jobs), int(os.environ.get("MAX_JOBS", "0")) or (os.cpu_count() or 1), 8))
+        with ThreadPoolExecutor(max_workers=workers) as pool:
+            list(pool.map(_run, jobs))
     tl = torch_lib_dir()
     tmp = HIP_LIB + ".tmp"
     _run(["g++", "-shared", "-o", tmp] + objs + [f"-L{tl}", "-l:libamdhip64.so"])
