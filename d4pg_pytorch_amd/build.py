@@ -51,6 +51,10 @@ def torch_lib_dir() -> str:
     return os.path.join(os.path.dirname(torch.__file__), "lib")
 
 
+#: translation units of csrc/fused.hip: -1 = C API + weight gradients, the others one hidden width each
+FUSED_PARTS = (-1, 13, 4, 8, 0)
+
+
 def build_hip(force: bool = False, verbose: bool = False) -> str:
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
     headers = [os.path.join(CSRC, h) for h in ("common.h", "loss_dev.h", "replay_dev.h")]
@@ -62,16 +66,24 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     objs = []
     hipcc = _hipcc()
     jobs = []
+    stamps = bool(os.environ.get("D4PG_STAMPS"))    # diagnostic build: per-layer clock stamps (bench/stamps.py)
     for s in srcs:
-        o = os.path.join(objdir, os.path.basename(s) + ".o")
-        if force or _stale(o, [s] + headers):
-            cmd = [hipcc, "-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-c", s, "-o", o]
-            if os.environ.get("D4PG_STAMPS"):      # diagnostic build: per-layer clock stamps (bench/stamps.py)
-                cmd.insert(1, "-DD4PG_STAMPS")
-            if verbose:
-                print(" ".join(cmd), flush=True)
-            jobs.append(cmd)
-        objs.append(o)
+        base = os.path.basename(s)
+        # fused.hip is built as five objects, one per hidden width of the phase kernels plus the main one
+        # (see the head of the file); the stamp build keeps it in one piece
+        parts = FUSED_PARTS if (base == "fused.hip" and not stamps) else (None,)
+        for part in parts:
+            o = os.path.join(objdir, base + ("" if part is None else f".part{part}") + ".o")
+            if force or _stale(o, [s] + headers):
+                cmd = [hipcc, "-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-c", s, "-o", o]
+                if part is not None:
+                    cmd.insert(1, f"-DD4PG_KSH_PART={part}")
+                if stamps:
+                    cmd.insert(1, "-DD4PG_STAMPS")
+                if verbose:
+                    print(" ".join(cmd), flush=True)
+                jobs.append(cmd)
+            objs.append(o)
     if jobs:        # the translation units are independent: compile them side by side
         from concurrent.futures import ThreadPoolExecutor
         workers = max(1, min(len(jobs), int(os.environ.get("MAX_JOBS", "0")) or (os.cpu_count() or 1), 8))

@@ -29,6 +29,17 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+// This file is compiled five times into five objects (build.py) to keep the build short: the phase
+// kernels are instantiated per hidden width (KSH = 13 / 4 / 8 K-steps, 0 = generic), and each width is
+// one translation unit (-DD4PG_KSH_PART=<KSH>) that holds nothing but those kernels and their launch
+// functions; the main unit (-DD4PG_KSH_PART=-1) holds the C API, the checks and the weight-gradient
+// kernel and reaches the others through `extern template`.  Without the macro everything is in one unit
+// (diagnostic and experiment builds).
+#ifndef D4PG_KSH_PART
+#define D4PG_KSH_PART 99
+#endif
+#define D4PG_MAIN_UNIT (D4PG_KSH_PART == 99 || D4PG_KSH_PART == -1)
+
 // Diagnostic build (-DD4PG_STAMPS): workgroup 0 records the 100 MHz wall clock at every layer
 // seam of the phase kernels; read back with d4pg_read_stamps (bench/stamps.py).
 #ifdef D4PG_STAMPS
@@ -38,6 +49,9 @@ __device__ unsigned long long g_stamps[2][32];
         if (blockIdx.x == 0 && threadIdx.x == 0) g_stamps[k][i] = wall_clock64();    \
     } while (0)
 #define STAMP_SYNC() __syncthreads()
+#if D4PG_KSH_PART != 99
+#error "the stamp build keeps everything in one translation unit (one g_stamps symbol)"
+#endif
 D4PG_API int d4pg_read_stamps(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps));
 }
@@ -1168,16 +1182,39 @@ static int launch_phase(K kernel, const Args& a, int grid, int nw, int lds, hipS
     return (int)hipGetLastError();
 }
 
-// KSN: register block of the narrow-K layers (2 covers inputs / logits up to 64 wide)
-#define DISPATCH_KSH(KERNEL, NWV, MTV, KSNV)                                                       \
-    do {                                                                                           \
-        if (ksh == 13) return launch_phase(KERNEL<NWV, MTV, 13, KSNV>, *a, grid, NWV, lds, stream); \
-        if (ksh == 4) return launch_phase(KERNEL<NWV, MTV, 4, KSNV>, *a, grid, NWV, lds, stream);   \
-        if (ksh == 8) return launch_phase(KERNEL<NWV, MTV, 8, KSNV>, *a, grid, NWV, lds, stream);   \
-        return launch_phase(KERNEL<NWV, MTV, 0, KSNV>, *a, grid, NWV, lds, stream);                 \
-    } while (0)
+// All variants of one phase kernel for ONE hidden width (KSN: register block of the narrow-K layers, 2
+// covers inputs / logits up to 64 wide).  Explicitly instantiated in the translation unit of that width.
+#define D4PG_PHASE_LAUNCHER(NAME, KERNEL, ARGS)                                                              \
+    template <int KSH>                                                                                        \
+    int NAME(const ARGS* a, int mt, int nw, int ksn, int grid, int lds, hipStream_t stream) {                 \
+        if (nw == NW_FEW) {                                                                                   \
+            if (ksn <= 2) return launch_phase(KERNEL<NW_FEW, 1, KSH, 2>, *a, grid, NW_FEW, lds, stream);      \
+            return launch_phase(KERNEL<NW_FEW, 1, KSH, 4>, *a, grid, NW_FEW, lds, stream);                    \
+        }                                                                                                     \
+        if (mt == 1) {                                                                                        \
+            if (ksn <= 2) return launch_phase(KERNEL<NW_MANY, 1, KSH, 2>, *a, grid, NW_MANY, lds, stream);    \
+            return launch_phase(KERNEL<NW_MANY, 1, KSH, 4>, *a, grid, NW_MANY, lds, stream);                  \
+        }                                                                                                     \
+        if (ksn <= 2) return launch_phase(KERNEL<NW_MANY, 2, KSH, 2>, *a, grid, NW_MANY, lds, stream);        \
+        return launch_phase(KERNEL<NW_MANY, 2, KSH, 4>, *a, grid, NW_MANY, lds, stream);                      \
+    }
+D4PG_PHASE_LAUNCHER(launch_critic_ksh, critic_phase_kernel, CriticPhaseArgs)
+D4PG_PHASE_LAUNCHER(launch_actor_ksh, actor_phase_kernel, ActorPhaseArgs)
 
-#define DISPATCH_PHASE(KERNEL, LDSFN)                                                       \
+#define D4PG_PHASE_INSTANCES(PREFIX, KSHV)                                                                      \
+    PREFIX template int launch_critic_ksh<KSHV>(const CriticPhaseArgs*, int, int, int, int, int, hipStream_t);  \
+    PREFIX template int launch_actor_ksh<KSHV>(const ActorPhaseArgs*, int, int, int, int, int, hipStream_t);
+#if D4PG_KSH_PART == -1          // main unit: the widths live in their own objects
+D4PG_PHASE_INSTANCES(extern, 13)
+D4PG_PHASE_INSTANCES(extern, 4)
+D4PG_PHASE_INSTANCES(extern, 8)
+D4PG_PHASE_INSTANCES(extern, 0)
+#elif D4PG_KSH_PART != 99        // the unit of one width
+D4PG_PHASE_INSTANCES(, D4PG_KSH_PART)
+#endif
+
+#if D4PG_MAIN_UNIT
+#define DISPATCH_PHASE(LAUNCHER, LDSFN)                                                     \
     const PhaseDims& d = a->d;                                                              \
     const int M = 16 * mt;                                                                  \
     if (mt != 1 && mt != 2) return -9;                                                      \
@@ -1187,16 +1224,10 @@ static int launch_phase(K kernel, const Args& a, int grid, int nw, int lds, hipS
     const int lds = LDSFN(d, M, nw);                                                        \
     const int grid = d.B / M + extra_blocks;                                                \
     const int ksh = (d.ldh - LDS_PAD) / 32;                                                 \
-    if (nw == NW_FEW) {                                                                     \
-        if (ksn <= 2) DISPATCH_KSH(KERNEL, NW_FEW, 1, 2);                                   \
-        DISPATCH_KSH(KERNEL, NW_FEW, 1, 4);                                                 \
-    }                                                                                       \
-    if (mt == 1) {                                                                          \
-        if (ksn <= 2) DISPATCH_KSH(KERNEL, NW_MANY, 1, 2);                                  \
-        DISPATCH_KSH(KERNEL, NW_MANY, 1, 4);                                                \
-    }                                                                                       \
-    if (ksn <= 2) DISPATCH_KSH(KERNEL, NW_MANY, 2, 2);                                      \
-    DISPATCH_KSH(KERNEL, NW_MANY, 2, 4);
+    if (ksh == 13) return LAUNCHER<13>(a, mt, nw, ksn, grid, lds, stream);                  \
+    if (ksh == 4) return LAUNCHER<4>(a, mt, nw, ksn, grid, lds, stream);                    \
+    if (ksh == 8) return LAUNCHER<8>(a, mt, nw, ksn, grid, lds, stream);                    \
+    return LAUNCHER<0>(a, mt, nw, ksn, grid, lds, stream);
 
 D4PG_API int d4pg_critic_phase(const CriticPhaseArgs* a, int mt, hipStream_t stream) {
     const int kmax = max_k32(a->d);
@@ -1218,7 +1249,7 @@ D4PG_API int d4pg_critic_phase(const CriticPhaseArgs* a, int mt, hipStream_t str
     const int extra_blocks = a->d.B / (mt == 2 ? 32 : 16) + n_warmers(a->d, mt);
     if (int prc = check_packed(a->pk, a->d)) return prc;
     if (a->ahead.mode != 0 && (a->ahead.h1 == nullptr || a->ahead.h2 == nullptr || a->ahead.lg == nullptr)) return -15;
-    DISPATCH_PHASE(critic_phase_kernel, phase_lds_bytes_critic)
+    DISPATCH_PHASE(launch_critic_ksh, phase_lds_bytes_critic)
 }
 
 D4PG_API int d4pg_actor_phase(const ActorPhaseArgs* a, int mt, hipStream_t stream) {
@@ -1246,7 +1277,7 @@ D4PG_API int d4pg_actor_phase(const ActorPhaseArgs* a, int mt, hipStream_t strea
     }
     const int n_ahead = a->ahead.mode != 0 ? a->d.B / (mt == 2 ? 32 : 16) : 0;
     const int extra_blocks = (a->tree.n > 0 ? 1 : 0) + n_ahead + n_warmers(a->d, mt);
-    DISPATCH_PHASE(actor_phase_kernel, phase_lds_bytes_actor)
+    DISPATCH_PHASE(launch_actor_ksh, phase_lds_bytes_actor)
 }
 
 D4PG_API int d4pg_phase_lds_bytes(const PhaseDims* d, int mt, int actor) {
@@ -1580,3 +1611,4 @@ D4PG_API int d4pg_wgrad(WgradGroup* g, hipStream_t stream) {
     if (nwv == 8) return launch_wgrad(wgrad_kernel<8>, 8, base, *g, stream);
     return launch_wgrad(wgrad_kernel<4>, 4, base, *g, stream);
 }
+#endif   // D4PG_MAIN_UNIT
