@@ -159,17 +159,24 @@ __device__ __forceinline__ void layer_ct(TileB<KS>& t, const __bf16* A, int lda,
     int nt = wave;
     if (nt >= L.ntiles) return;
     for (;;) {
-        f32x4 acc[MT];
+        // two accumulators per row tile (even / odd K-steps): a dependent MFMA waits out the whole
+        // pipeline of the one before it
+        f32x4 acc[MT], acc1[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = acc1[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(A + (mt * 16 + c) * lda + ks * 32 + 8 * kg);
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, t.b[ks], acc[mt], 0, 0, 0);
+                if (ks & 1)
+                    acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, t.b[ks], acc1[mt], 0, 0, 0);
+                else
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, t.b[ks], acc[mt], 0, 0, 0);
             }
         }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] += acc1[mt];
         const float bias = use_bias(L, nt, c, t.bias);
         const int nn = nt + NW;
         if (nn < L.ntiles) {
