@@ -1531,7 +1531,9 @@ __global__ __launch_bounds__(64 * NWV) void wgrad_kernel(const WgradGroup g) {
             for (int w = 0; w < NWV; ++w) gv += red[(w * 16 + reg) * 64 + lane];
             const int cm = cm0 + i;
             if (cm < d.M && cn < d.N) {
-                d.C[(size_t)cm * d.ldc + cn] = gv;
+                // the gradient itself goes to memory only when something outside reads it (the all-reduce of
+                // the gradient-exchange mode); with the optimiser fused below nothing does
+                if (!fuse) d.C[(size_t)cm * d.ldc + cn] = gv;
                 if (fuse) {
                     float tv;
                     const float pv = adam_apply(o, d.w_off + (long long)cm * d.ldc + cn, ast[i], gv, step_size,
@@ -1566,7 +1568,7 @@ __global__ __launch_bounds__(64 * NWV) void wgrad_kernel(const WgradGroup g) {
                 float gb = 0.f;
     #pragma unroll
                 for (int w = 0; w < NWV; ++w) gb += cs[w * 32 + threadIdx.x];
-                d.rowsum[cm] = gb;
+                if (!fuse) d.rowsum[cm] = gb;
                 if (fuse) {
                     float tv;
                     adam_elem(o, d.b_off + cm, gb, step_size, inv_sqrt_bc2, tv);
