@@ -1425,7 +1425,7 @@ __device__ __forceinline__ void wgrad_finish_role(const WgradAdam& o, float* cs)
     }
 }
 
-// NWV waves split the batch (K); waves 0..3 then finish the tile (sum of the NWV partial
+// NWV waves split the batch (K), then all of them finish the tile (sum of the NWV partial
 // tiles, optimiser, shadows).  More waves = more stash loads in flight per CU: the loop is
 // bound by the latency of those loads (the stashes were just written by other CUs), so NWV
 // grows with the batch.
@@ -1470,16 +1470,22 @@ __global__ __launch_bounds__(64 * NWV) void wgrad_kernel(const WgradGroup g) {
     const int ksteps = g.Bp >> 4;              // k-steps of 16
     const __bf16* arow = d.AT + ((size_t)tm * ksteps * 64 + lane) * 8;
     const __bf16* brow = d.BT + ((size_t)tn * ksteps * 64 + lane) * 8;
-    // fused optimiser: this thread finishes rows pm0 .. pm0+3 of column pn of the tile
+    // Finishing the tile (sum of the NWV partial tiles, optimiser, shadows) is spread over ALL waves:
+    // wave w owns accumulator registers w * EPT .. w * EPT + EPT - 1 of every lane, i.e. EPT rows of
+    // column pn (register q of a 32x32 accumulator is row 8 * (q / 4) + 4 * h + q % 4).
+    constexpr int EPT = 16 / NWV;
     const WgradAdam& o = g.opt;
     const bool fuse = o.p != nullptr;
-    const int pm0 = tm * 32 + 8 * wave + 4 * h, pn = tn * 32 + r;
-    AdamState ast[4];
+    const int pn = tn * 32 + r;
+    auto row_of_reg = [&](int q) { return tm * 32 + 8 * (q >> 2) + 4 * h + (q & 3); };
+    AdamState ast[EPT];
     float step_size = 0.f, inv_sqrt_bc2 = 0.f;
-    if (fuse && wave < 4) {
+    if (fuse) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (pm0 + i < d.M && pn < d.N) ast[i] = adam_fetch(o, d.w_off + (long long)(pm0 + i) * d.ldc + pn);
+        for (int i = 0; i < EPT; ++i) {
+            const int pm = row_of_reg(wave * EPT + i);
+            if (pm < d.M && pn < d.N) ast[i] = adam_fetch(o, d.w_off + (long long)pm * d.ldc + pn);
+        }
         step_size = o.st->bc1;
         inv_sqrt_bc2 = o.st->bc2;
     }
@@ -1514,22 +1520,21 @@ __global__ __launch_bounds__(64 * NWV) void wgrad_kernel(const WgradGroup g) {
     }
     __syncthreads();
     STAMP(1, 23);
-    if (wave < 4) {
+    {
         if (fuse) {
             step_size = o.lr / step_size;
             inv_sqrt_bc2 = 1.f / sqrtf(inv_sqrt_bc2);
         }
-        const int wv = threadIdx.x >> 6;
-        const int cn = tn * 32 + r;
-        const int cm0 = tm * 32 + 8 * wv + 4 * h;      // this thread finishes rows cm0 .. cm0+3 of column cn
-        f32x4 pnew = {0.f, 0.f, 0.f, 0.f};
-    #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int reg = 4 * wv + i;
+        const int cn = pn;
+        float pnew[EPT];
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            const int reg = wave * EPT + i;
             float gv = 0.f;
-    #pragma unroll
+#pragma unroll
             for (int w = 0; w < NWV; ++w) gv += red[(w * 16 + reg) * 64 + lane];
-            const int cm = cm0 + i;
+            const int cm = row_of_reg(reg);
+            pnew[i] = 0.f;
             if (cm < d.M && cn < d.N) {
                 // the gradient itself goes to memory only when something outside reads it (the all-reduce of
                 // the gradient-exchange mode); with the optimiser fused below nothing does
@@ -1548,25 +1553,35 @@ __global__ __launch_bounds__(64 * NWV) void wgrad_kernel(const WgradGroup g) {
             }
         }
         if (fuse && d.sb_off >= 0 && cn >= d.sb_c0 && cn < d.sb_c1 && cn < d.N) {
-            // transposed shadow: 4 consecutive output rows (cm0 % 4 == 0) of one input column are 4
-            // consecutive k of one packed row -> one 8-byte store
-            __bf16* dst = o.p_shadow + d.sb_off + packed_off(cn - d.sb_c0, cm0, d.sb_ld >> 5);
-            if (cm0 + 3 < d.M) {
-                bf16x4 pk;
-    #pragma unroll
-                for (int i = 0; i < 4; ++i) pk[i] = (__bf16)pnew[i];
-                *reinterpret_cast<bf16x4*>(dst) = pk;
+            // transposed shadow: output rows are the k of a packed row
+            if constexpr (EPT == 4) {
+                // 4 consecutive output rows (multiple of 4) of one input column: one 8-byte store
+                const int cm0 = row_of_reg(wave * EPT);
+                __bf16* dst = o.p_shadow + d.sb_off + packed_off(cn - d.sb_c0, cm0, d.sb_ld >> 5);
+                if (cm0 + 3 < d.M) {
+                    bf16x4 pk;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) pk[i] = (__bf16)pnew[i];
+                    *reinterpret_cast<bf16x4*>(dst) = pk;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (cm0 + i < d.M) dst[i] = (__bf16)pnew[i];
+                }
             } else {
-    #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (cm0 + i < d.M) dst[i] = (__bf16)pnew[i];
+#pragma unroll
+                for (int i = 0; i < EPT; ++i) {
+                    const int cm = row_of_reg(wave * EPT + i);
+                    if (cm < d.M)
+                        o.p_shadow[d.sb_off + packed_off(cn - d.sb_c0, cm, d.sb_ld >> 5)] = (__bf16)pnew[i];
+                }
             }
         }
         if (d.rowsum != nullptr && tn == 0 && threadIdx.x < 32) {
             const int cm = tm * 32 + threadIdx.x;
             if (cm < d.M) {
                 float gb = 0.f;
-    #pragma unroll
+#pragma unroll
                 for (int w = 0; w < NWV; ++w) gb += cs[w * 32 + threadIdx.x];
                 if (!fuse) d.rowsum[cm] = gb;
                 if (fuse) {
