@@ -63,11 +63,15 @@ D4PG_API int d4pg_read_stamps(unsigned long long* out) {
 // Waves per workgroup of the phase kernels.  Every wave keeps one weight tile (13 KB at H = 400) in
 // flight, and a layer is bound by the latency of those loads: measured per update at batch 256,
 // 8 waves 66.2 us, 12 waves 63.6 us, 16 waves 64.2 us (16 waves = 4 per SIMD leave 128 registers per
-// wave, which the two prefetch slots of the layer chain overflow; 12 = 3 per SIMD leave 168).
+// wave, which the two prefetch slots of the layer chain overflow; 12 = 3 per SIMD leave 168; 13 would
+// balance the 25 tiles of a 400-wide layer over two rounds but is capped at 128 registers too: 57.5 us).
 // The kernels are instantiated for 12 and for 8 waves; the host picks 8 once the grid has more
 // workgroups than the chip has CUs (batch 4096: 12 waves 107.8 us, 8 waves 93.5 us per update; capping
 // the 8-wave variant at 128 registers so that two workgroups fit on a CU costs 14 spills: 97.8 us).
-constexpr int NW_FEW = 12;     // grid <= 256 workgroups
+#ifndef D4PG_NW_FEW
+#define D4PG_NW_FEW 12
+#endif
+constexpr int NW_FEW = D4PG_NW_FEW;     // grid <= 256 workgroups
 constexpr int NW_MANY = 8;
 constexpr int LDS_PAD = 8;     // bf16 elements appended to every LDS row (16 B: breaks the bank stride)
 
