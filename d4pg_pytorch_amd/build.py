@@ -19,7 +19,7 @@ from typing import List
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-HIP_SOURCES = ["gemm.hip", "loss.hip", "optim.hip", "replay.hip", "nstep.hip", "fused.hip"]
+HIP_SOURCES = ["gemm.hip", "loss.hip", "optim.hip", "replay.hip", "nstep.hip", "fused.hip", "fused32.hip"]
 HOST_SOURCES = ["host_runtime.cpp"]
 HIP_LIB = os.path.join(CSRC, "libd4pg_hip.so")
 HOST_LIB = os.path.join(CSRC, "libd4pg_host.so")
@@ -51,13 +51,14 @@ def torch_lib_dir() -> str:
     return os.path.join(os.path.dirname(torch.__file__), "lib")
 
 
-#: translation units of csrc/fused.hip: -1 = C API + weight gradients, the others one hidden width each
-FUSED_PARTS = (-1, 13, 4, 8, 0)
+#: translation units of csrc/fused.hip / csrc/fused32.hip: -1 = C API + weight gradients, the others one
+#: hidden width each (0 = the run-time-width variant, bf16 pipeline only)
+FUSED_PARTS = {"fused.hip": (-1, 13, 4, 8, 0), "fused32.hip": (-1, 13, 4, 8)}
 
 
 def build_hip(force: bool = False, verbose: bool = False) -> str:
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    headers = [os.path.join(CSRC, h) for h in ("common.h", "loss_dev.h", "replay_dev.h")]
+    headers = [os.path.join(CSRC, h) for h in ("common.h", "loss_dev.h", "replay_dev.h", "phase_common.h", "mlp32_dev.h")]
     deps = srcs + headers
     if not force and not _stale(HIP_LIB, deps):
         return HIP_LIB
@@ -71,7 +72,7 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
         base = os.path.basename(s)
         # fused.hip is built as five objects, one per hidden width of the phase kernels plus the main one
         # (see the head of the file); the stamp build keeps it in one piece
-        parts = FUSED_PARTS if (base == "fused.hip" and not stamps) else (None,)
+        parts = FUSED_PARTS[base] if (base in FUSED_PARTS and not (stamps and base == "fused.hip")) else (None,)
         for part in parts:
             o = os.path.join(objdir, base + ("" if part is None else f".part{part}") + ".o")
             if force or _stale(o, [s] + headers):

@@ -96,20 +96,21 @@ EXTENSION_DEFAULTS: Dict[str, Any] = {
     "max_env_steps_per_agent": 1_000_000,  # agent.py:60 bound, kept as a safety stop
     "updates_per_env_step": None,    # optional throttle: learner waits so updates <= ratio * env_steps
     # --- MI355X execution ---
-    "compute_dtype": "auto",         # GPU learner: "bf16" (fused row-local pipeline: bf16 MFMA operands, fp32 master
-                                     # weights / Adam / logits / loss; 3x the update rate) | "fp32" (exact f32 MFMA
-                                     # kernels, tracks eager PyTorch to 2e-5) | "auto": bf16 where its shape limits
-                                     # (batch a multiple of 16, hidden layers that fit the LDS) hold, else fp32
+    "compute_dtype": "auto",         # GPU learner: "fp32" = "auto" (reference precision, d4pg.py:73-77: exact f32
+                                     # MFMA, fused row-local pipeline, tracks eager PyTorch to rounding) | "bf16"
+                                     # (opt-in: the same pipeline with bf16 MFMA operands; fp32 master weights, Adam,
+                                     # logits and loss)
     "use_hip_graph": True,           # replay the whole update as one captured HIP graph
-    "fused_learner": "auto",         # "auto": HIP kernels on cuda, torch ops on cpu; "torch": force eager torch
+    "fused_learner": "auto",         # "auto": HIP kernels on cuda, torch ops on cpu; "torch": force eager torch;
+                                     # "layers": the fp32 kernels with one launch per layer (any shape)
     "metrics_interval": 100,         # device-side metric accumulator is read back every N updates
     "control_interval": 1024,        # several learners: updates between two agreements on the stop flag (one 8-byte
                                      # all-reduce; a rank must not leave the collectives of the others on its own)
     "ring_capacity": 4096,           # rows per explorer->replay shared-memory ring
     "ingest_chunk": 1024,            # rows per pinned H2D staging chunk
     "ingest_interval": 32,           # learner updates between two drains of the explorer rings
-    "phase_tile_rows": "auto",       # bf16 pipeline: batch rows per workgroup, "auto" | 16 | 32
-    "sample_ahead": 32,              # uniform replay, bf16 pipeline: batches drawn per sampling launch = updates per
+    "phase_tile_rows": "auto",       # batch rows per phase workgroup: "auto" | 4 | 8 | 16 (fp32) | 16 | 32 (bf16)
+    "sample_ahead": 32,              # uniform replay, fused pipelines: batches drawn per sampling launch = updates per
                                      # graph replay (1: every update); 8: 55.3 us per update, 32: 54.4 us
     # --- lifecycle ---
     "resume": None,                  # path to a learner checkpoint bundle to resume from

@@ -25,6 +25,7 @@
 #include "common.h"
 #include "loss_dev.h"
 #include "replay_dev.h"
+#include "phase_common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -353,9 +354,6 @@ struct Chain {
     }
 };
 
-// tanh through one v_exp_f32: 1 - 2 / (e^{2x} + 1); exact at +-inf, |error| < 2e-7
-__device__ __forceinline__ float fast_tanh(float x) { return 1.f - 2.f / (__expf(2.f * x) + 1.f); }
-
 // ---- epilogue helpers -------------------------------------------------------------------
 // 4 consecutive rows (row0..row0+3) of one column -> LDS column write
 __device__ __forceinline__ void put_lds4(__bf16* buf, int ld, int row0, int col, const f32x4& v) {
@@ -378,73 +376,6 @@ __device__ __forceinline__ void put_stash4(__bf16* XT, int Kb, int col, int b0, 
     *reinterpret_cast<bf16x4*>(XT + stash_off(col, b0, Kb)) = o;
 }
 
-// Batch rows read straight out of the gathered chunk buffers of csrc/replay.hip (packed rows
-// [s | a | r | done | gamma^k | s' | weight | slot]), so that no per-update kernel has to
-// copy them into separate input matrices.  Which chunk buffer and which batch of the chunk
-// follow from the device step counter, exactly as in batch_unpack_kernel.
-struct PackedIn {
-    const float* in0;        // gathered chunk, even chunks  [world][K][Bl][row_ld + 4]
-    const float* in1;        // gathered chunk, odd chunks
-    DevState* st;
-    long long step0;         // device step counter at the first batch of chunk 0
-    int K, Bl, row_ld;
-    int enabled;             // 0: the plain input arrays of the phase arguments are used
-    int do_tick;             // the critic phase performs the per-update tick (block 0, thread 0)
-    float beta1, beta2, per_b0, per_b1;
-    int pad_;
-    long long total_steps;
-};
-
-// Where batch row b of some input lives:  base + (b / Bl) * rank_stride + (b % Bl) * stride.
-struct RowSrc {
-    const float* base;
-    long long stride, rank_stride;
-    int Bl;
-};
-__device__ __forceinline__ RowSrc plain_src(const float* base, long long stride, int B) {
-    return RowSrc{base, stride, 0, B > 0 ? B : 1};
-}
-// delta = 1: the batch of the NEXT update
-__device__ __forceinline__ RowSrc packed_src(const PackedIn& p, int col0, int delta = 0) {
-    const long long s = p.st->step_done - p.step0 + delta;
-    // 32-bit division while the count fits (a 64-bit one is a ~150-instruction routine at the head of
-    // the dependent chain of every phase kernel)
-    int j, odd;
-    if (((unsigned long long)s >> 32) == 0) {
-        const unsigned q = (unsigned)s / (unsigned)p.K;
-        j = (int)((unsigned)s - q * (unsigned)p.K);
-        odd = (int)(q & 1u);
-    } else {
-        j = (int)(s % p.K);
-        odd = (int)((s / p.K) & 1);
-    }
-    const float* chunk = odd ? p.in1 : p.in0;
-    const long long ldp = p.row_ld + 4;
-    return RowSrc{chunk + (long long)j * p.Bl * ldp + col0, ldp, (long long)p.K * p.Bl * ldp, p.Bl};
-}
-__device__ __forceinline__ const float* row_of(const RowSrc& r, int b) {
-    const int q = b / r.Bl;
-    return r.base + q * r.rank_stride + (b - q * r.Bl) * r.stride;
-}
-
-struct PhaseDims {
-    int B;            // batch rows (multiple of 16*MT)
-    int Bp;           // batch rows rounded up to a multiple of 32 (K of the weight-gradient GEMMs, stash_off)
-    int S, A, H, NO;  // state, action, hidden, critic outputs (atoms or 1)
-    int ldx_in;       // leading dimension of the fp32 input matrices (floats)
-    int ldx;          // LDS leading dim of the input tile   = pad32(S + A) + LDS_PAD
-    int ldh;          // LDS leading dim of the hidden tiles  = pad32(H) + LDS_PAD
-    int ldd;          // LDS leading dim of the dlogits tile  = pad32(NO) + LDS_PAD
-    int lda_;         // LDS leading dim of the d-action tile = pad32(A) + LDS_PAD
-    int nop;          // fp32 logits row stride in LDS        = pad16(NO)
-    int distributional;
-    int use_ce;
-    float v_min, v_max;
-    float fixed_gamma;   // < 0: per-sample gamma
-    float inv_B;         // 1 / global batch
-    float min_value, max_value;   // scalar-critic target clamp
-};
-
 // The online critic's forward pass on the batch of update u + 1 needs nothing but that batch and
 // the critic weights as update u leaves them, and those are final once the critic optimiser of
 // update u has run.  When the batches are drawn ahead (PackedIn), B / M extra workgroups of the
@@ -460,7 +391,6 @@ struct CriticAhead {
     __bf16* h2;      // [B][ldh]
     float* lg;       // [B][nop] logits
 };
-constexpr int AHEAD_STEP = 0, AHEAD_ROWS = 1;      // DevState::pad_ slots of the tag
 
 // The online actor's forward pass a = pi(s) does not depend on the critic update, so it does
 // not belong on the critical path critic phase -> critic optimiser -> actor phase: it runs in
@@ -504,11 +434,6 @@ struct CriticPhaseArgs {
     CriticAhead ahead;     // tiles made by the previous update's actor phase launch (consumed when the tag matches)
 };
 
-// zero `bytes` (multiple of 16) of LDS
-__device__ __forceinline__ void zero_block(void* buf, int bytes) {
-    for (int i = threadIdx.x * 16; i < bytes; i += blockDim.x * 16)
-        *reinterpret_cast<f32x4*>((char*)buf + i) = f32x4{0.f, 0.f, 0.f, 0.f};
-}
 // zero the K-padding tail of every row of an M-row bf16 LDS tile: columns [c0 & ~7, ld)
 // (ld is a multiple of 8, so every chunk is an aligned 16-byte store; columns c0 & ~7 .. c0
 // are rewritten by the producing layer's epilogue afterwards)
@@ -518,12 +443,6 @@ __device__ __forceinline__ void zero_tail(__bf16* buf, int ld, int M, int c0) {
         const int r = i / chunks, c = i - r * chunks;
         *reinterpret_cast<f32x4*>(buf + r * ld + a0 + 8 * c) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-}
-
-// flat copy of `bytes` (multiple of 16, both sides 16-byte aligned)
-__device__ __forceinline__ void copy16(void* dst, const void* src, int bytes) {
-    for (int i = threadIdx.x * 16; i < bytes; i += blockDim.x * 16)
-        *reinterpret_cast<f32x4*>((char*)dst + i) = *reinterpret_cast<const f32x4*>((const char*)src + i);
 }
 
 // Load `ncols` fp32 columns of M batch rows into a bf16 LDS tile whose remaining columns (up to
@@ -1155,13 +1074,6 @@ static int check_layer(const LayerW& L, int k32_max) {
     if (((uintptr_t)L.W) & 15) return -7;
     return 0;
 }
-static int check_packed(const PackedIn& p, const PhaseDims& d) {
-    if (p.do_tick && p.st == nullptr) return -12;
-    if (!p.enabled) return 0;
-    if (p.in0 == nullptr || p.in1 == nullptr || p.st == nullptr) return -12;
-    if (p.K < 1 || p.Bl < 1 || d.B % p.Bl || p.row_ld < 2 * d.S + d.A + 3) return -13;
-    return 0;
-}
 static int max3i(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
 // hidden-K layers run the compile-time path: their K-steps must be the kernel's
 static int check_hidden(const LayerW& L, int ksh) { return L.ks == ksh ? 0 : -10; }
@@ -1180,17 +1092,6 @@ static int n_warmers(const PhaseDims& d, int mt) {
         return v < 0 ? 0 : (v > 256 ? 256 : (v + 7) & ~7);
     }();
     return n;
-}
-
-template <typename K, typename Args>
-static int launch_phase(K kernel, const Args& a, int grid, int nw, int lds, hipStream_t stream) {
-    if (lds > 160 * 1024) return -8;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
-    }
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * nw), lds, stream, a);
-    return (int)hipGetLastError();
 }
 
 // All variants of one phase kernel for ONE hidden width (KSN: register block of the narrow-K layers, 2
@@ -1317,28 +1218,6 @@ struct WgradDesc {
 };
 constexpr int WG_MAX = 3;
 
-// Optimiser state for the fused variant: when `p` is non-null every workgroup applies
-// Adam + Polyak + the bf16 shadow refresh to the 32x32 tile of W it has just reduced
-// (and the tn == 0 workgroups to the bias rows), so no separate optimiser launch is
-// needed.  Only valid without data parallelism (the gradient must not need an all-reduce).
-struct WgradAdam {
-    float* p;            // flat online parameters (whole buffer)
-    float* m;
-    float* v;
-    float* t;            // flat target parameters
-    __bf16* p_shadow;
-    __bf16* t_shadow;
-    DevState* st;
-    float* metrics;              // finishing launch only
-    const float* per_loss;
-    const float* weights;
-    const float* q_val;
-    int B;
-    float inv_B;
-    float lr, beta1, beta2, eps, tau;
-    int finish_step;
-};
-
 struct WgradGroup {
     WgradDesc p[WG_MAX];
     int count, total_tiles;
@@ -1354,80 +1233,6 @@ struct WgradGroup {
     int smp_rows;              // = smp->B (host copy: smp points to device memory)
     int pad2_;
 };
-
-// optimiser state of one parameter, fetched at kernel entry (ahead of the stash loads and the
-// MFMA loop, so its memory latency overlaps theirs)
-struct AdamState {
-    float m, v, p, t;
-};
-__device__ __forceinline__ AdamState adam_fetch(const WgradAdam& o, long long idx) {
-    return AdamState{o.m[idx], o.v[idx], o.p[idx], o.t[idx]};
-}
-__device__ __forceinline__ float adam_apply(const WgradAdam& o, long long idx, const AdamState& s, float g,
-                                            float step_size, float inv_sqrt_bc2, float& t_out) {
-    float m = s.m, v = s.v, p = s.p;
-    m = o.beta1 * m + (1.f - o.beta1) * g;
-    v = o.beta2 * v + (1.f - o.beta2) * g * g;
-    p = p - step_size * (m / (sqrtf(v) * inv_sqrt_bc2 + o.eps));
-    o.m[idx] = m;
-    o.v[idx] = v;
-    o.p[idx] = p;
-    const float t = (1.f - o.tau) * s.t + o.tau * p;
-    o.t[idx] = t;
-    t_out = t;
-    return p;
-}
-__device__ __forceinline__ float adam_elem(const WgradAdam& o, long long idx, float g, float step_size,
-                                           float inv_sqrt_bc2, float& t_out) {
-    float m = o.m[idx], v = o.v[idx], p = o.p[idx];
-    m = o.beta1 * m + (1.f - o.beta1) * g;
-    v = o.beta2 * v + (1.f - o.beta2) * g * g;
-    p = p - step_size * (m / (sqrtf(v) * inv_sqrt_bc2 + o.eps));
-    o.m[idx] = m;
-    o.v[idx] = v;
-    o.p[idx] = p;
-    const float t = (1.f - o.tau) * o.t[idx] + o.tau * p;
-    o.t[idx] = t;
-    t_out = t;
-    return p;
-}
-
-// End of an update: fold its losses into the metric sums and publish the step (step_done is read
-// only by the first kernel of the next update).  Run by ONE EXTRA workgroup of the finishing launch,
-// from its start: in a workgroup that also owns a tile this is ~1 us at the very end of the kernel.
-template <int NWV>
-__device__ __forceinline__ void wgrad_finish_role(const WgradAdam& o, float* cs) {
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // fold this update's losses into the metric sums and publish the step
-    // (step_done is read only by the first kernel of the next update)
-    __syncthreads();
-    float vl = 0.f, pl = 0.f;
-    for (int b = threadIdx.x; b < o.B; b += blockDim.x) {
-        vl += o.per_loss[b] * (o.weights ? o.weights[b] : 1.f);
-        pl -= o.q_val[b];
-    }
-    vl = wave_sum(vl);
-    pl = wave_sum(pl);
-    if (lane == 0) {
-        cs[wave] = vl;
-        cs[NWV + wave] = pl;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (o.metrics != nullptr) {
-            float svl = 0.f, spl = 0.f;
-            for (int w = 0; w < NWV; ++w) {
-                svl += cs[w];
-                spl += cs[NWV + w];
-            }
-            o.metrics[MET_VALUE_LOSS] += svl * o.inv_B;
-            o.metrics[MET_POLICY_LOSS] += spl * o.inv_B;
-            o.metrics[MET_COUNT] += 1.f;
-        }
-        o.st->step_done = o.st->step_cur;
-    }
-}
 
 // NWV waves split the batch (K), then all of them finish the tile (sum of the NWV partial
 // tiles, optimiser, shadows).  More waves = more stash loads in flight per CU: the loop is
@@ -1550,8 +1355,8 @@ __global__ __launch_bounds__(64 * NWV) void wgrad_kernel(const WgradGroup g) {
                     pnew[i] = pv;
                     if (d.sf_off >= 0) {
                         const long long so = d.sf_off + packed_off(cm, cn, d.sf_ld >> 5);
-                        o.p_shadow[so] = (__bf16)pv;
-                        o.t_shadow[so] = (__bf16)tv;
+                        ((__bf16*)o.p_shadow)[so] = (__bf16)pv;
+                        ((__bf16*)o.t_shadow)[so] = (__bf16)tv;
                     }
                 }
             }
@@ -1561,7 +1366,7 @@ __global__ __launch_bounds__(64 * NWV) void wgrad_kernel(const WgradGroup g) {
             if constexpr (EPT == 4) {
                 // 4 consecutive output rows (multiple of 4) of one input column: one 8-byte store
                 const int cm0 = row_of_reg(wave * EPT);
-                __bf16* dst = o.p_shadow + d.sb_off + packed_off(cn - d.sb_c0, cm0, d.sb_ld >> 5);
+                __bf16* dst = (__bf16*)o.p_shadow + d.sb_off + packed_off(cn - d.sb_c0, cm0, d.sb_ld >> 5);
                 if (cm0 + 3 < d.M) {
                     bf16x4 pk;
 #pragma unroll
@@ -1577,7 +1382,7 @@ __global__ __launch_bounds__(64 * NWV) void wgrad_kernel(const WgradGroup g) {
                 for (int i = 0; i < EPT; ++i) {
                     const int cm = row_of_reg(wave * EPT + i);
                     if (cm < d.M)
-                        o.p_shadow[d.sb_off + packed_off(cn - d.sb_c0, cm, d.sb_ld >> 5)] = (__bf16)pnew[i];
+                        ((__bf16*)o.p_shadow)[d.sb_off + packed_off(cn - d.sb_c0, cm, d.sb_ld >> 5)] = (__bf16)pnew[i];
                 }
             }
         }

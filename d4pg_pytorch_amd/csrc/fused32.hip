@@ -1,0 +1,1003 @@
+// Fused, row-local learner update in reference precision (fp32 operands, fp32 accumulation; gfx950).
+//
+// The same decomposition as csrc/fused.hip — everything but the weight gradients is local to a batch
+// row, so a workgroup takes a tile of rows through WHOLE chains of layers with the activations in LDS,
+// and an update is four launches (critic phase, weight gradients + optimiser, actor phase, weight
+// gradients + optimiser) — but every product is an exact f32 multiply-add on the matrix cores:
+//
+//   phases : v_mfma_f32_4x4x1_16b_f32 on tiles of 4 * MT rows (csrc/mlp32_dev.h); weights streamed from
+//            fp32 copies packed in fragment order; activations, logits, losses, dX in fp32 in LDS
+//   wgrad  : v_mfma_f32_32x32x2_f32 on fp32 stashes written by the phases in operand-fragment order,
+//            Adam + Polyak + refresh of the packed copies fused into the tile epilogue
+//
+// The reference computes in fp32 throughout (models/d4pg/d4pg.py:73-77 `.float()`,
+// models/d4pg/networks.py:23-25 fp32 nn.Linear); this pipeline tracks an eager fp32 PyTorch update to
+// rounding (tests/test_hip_f32.py).  A layer costs what it takes to stream its fp32 weights through the
+// one CU that owns the row tile (a CU's vector cache delivers ~130 GB/s: 5.3 us for 400 x 400, twice the
+// bf16 copies of csrc/fused.hip); the MFMA work of a 4-row tile (2.3 us) hides under it.
+#include "common.h"
+#include "loss_dev.h"
+#include "replay_dev.h"
+#include "phase_common.h"
+#include "mlp32_dev.h"
+
+// Compiled once per hidden width (build.py, -DD4PG_KSH_PART=<KSH>), like csrc/fused.hip: the unit of one
+// width holds the phase kernels for that width, the main unit (-1) the C API and the weight gradients.
+#ifndef D4PG_KSH_PART
+#define D4PG_KSH_PART 99
+#endif
+#define D4PG_MAIN_UNIT (D4PG_KSH_PART == 99 || D4PG_KSH_PART == -1)
+
+constexpr int NW32 = 8;          // waves per phase workgroup: one unit (column tile or K-slice) each
+constexpr int LDS_PAD32 = 4;     // floats appended to every LDS row: the 4 rows of one wide read hit disjoint banks
+
+// chunks per K-slice of a single-tile layer whose K is the hidden width (KSH chunks dealt to NW32 waves)
+constexpr int split_nch(int ksh) { return (ksh + NW32 - 1) / NW32; }
+
+// Prefetch state along the chain of layers: two register sets alternate, the layer running out of
+// slot X has the first chunk of its successor fetched into slot 1 - X.
+template <int MT, int KSH, int KSN>
+struct Chain32 {
+    Pre32 t0, t1;
+    float* red;
+    int wave, lane;
+    __device__ __forceinline__ Chain32(float* red_) : red(red_) {
+        lane = threadIdx.x & 63;
+        wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    }
+    template <int SLOT>
+    __device__ __forceinline__ void prefetch(const LayerW32& L) {
+        if constexpr (SLOT == 0)
+            t0 = fetch_first(L, wave, lane);
+        else
+            t1 = fetch_first(L, wave, lane);
+    }
+    // K = hidden width, N = hidden width: KSH chunks per column tile
+    template <int SLOT, typename F, typename P>
+    __device__ __forceinline__ void hidden(const float* A, int lda, const LayerW32& L, F&& epi, P&& pre) {
+        layer32<NW32, MT, KSH, false>(SLOT == 0 ? t0 : t1, A, lda, L, red, epi, pre);
+    }
+    // K = hidden width, N <= 64 (actions, atoms): K-slices of one column tile
+    template <int SLOT, typename F, typename P>
+    __device__ __forceinline__ void split(const float* A, int lda, const LayerW32& L, F&& epi, P&& pre) {
+        layer32<NW32, MT, split_nch(KSH), false>(SLOT == 0 ? t0 : t1, A, lda, L, red, epi, pre);
+    }
+    // K <= 32 * KSN (inputs, actions, atoms), N = hidden width
+    template <int SLOT, typename F, typename P>
+    __device__ __forceinline__ void narrow(const float* A, int lda, const LayerW32& L, F&& epi, P&& pre) {
+        layer32<NW32, MT, KSN, true>(SLOT == 0 ? t0 : t1, A, lda, L, red, epi, pre);
+    }
+};
+
+// ---- LDS / stash helpers ------------------------------------------------------------------------
+// 4 consecutive rows of one column -> LDS (consecutive lanes = consecutive columns: no bank conflicts)
+__device__ __forceinline__ void put_lds4(float* buf, int ld, int row0, int col, const f32x4& v) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) buf[(row0 + r) * ld + col] = v[r];
+}
+// Activation / gradient stashes for the weight-gradient kernel: element (feature col, batch row b) lives
+// where v_mfma_f32_32x32x2_f32 wants it when 16-byte loads feed four MFMAs each, i.e.
+// [col / 32][b / 8][lane = 32 * ((b % 8) / 4) + col % 32][b % 4]: one wave-wide load is a contiguous 1 KB
+// and the 4 rows a lane holds after an MFMA of the phases are one 16-byte store.  (The k order inside a
+// group of 8 rows is permuted the same way in both operands, which a sum over k does not see.)
+__device__ __forceinline__ size_t stash32_off(int col, int b, int Kb) {
+    return ((size_t)(col >> 5) * (Kb >> 3) + (b >> 3)) * 256 + ((((b >> 2) & 1) << 5) + (col & 31)) * 4 + (b & 3);
+}
+__device__ __forceinline__ void put_stash4(float* XT, int Kb, int col, int b0, const f32x4& v) {
+    *reinterpret_cast<f32x4*>(XT + stash32_off(col, b0, Kb)) = v;
+}
+// zero columns [c0 & ~3, ld) of every row of an M-row LDS tile (K padding; an epilogue rewrites c0 & ~3 .. c0)
+__device__ __forceinline__ void zero_tail(float* buf, int ld, int M, int c0) {
+    const int a0 = c0 & ~3, chunks = (ld - a0) >> 2;
+    for (int i = threadIdx.x; i < M * chunks; i += blockDim.x) {
+        const int r = i / chunks, c = i - r * chunks;
+        *reinterpret_cast<f32x4*>(buf + r * ld + a0 + 4 * c) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+// `ncols` columns of M batch rows -> LDS tile (remaining columns zero), optionally also into a stash
+__device__ __forceinline__ void load_input(const RowSrc& src, int row0, int M, int ncols, float* dst, int ld_dst,
+                                           float* stashT, int Kb) {
+    for (int i = threadIdx.x; i < M * ld_dst; i += blockDim.x) {
+        const int r = i / ld_dst, c = i - r * ld_dst;
+        float v = 0.f;
+        if (c < ncols) {
+            v = row_of(src, row0 + r)[c];
+            if (stashT != nullptr) stashT[stash32_off(c, row0 + r, Kb)] = v;
+        }
+        dst[r * ld_dst + c] = v;
+    }
+}
+// L2 warmer: slice `slice` of `nslices` of a packed weight copy is read and discarded (csrc/fused.hip, warm_layer)
+__device__ __forceinline__ void warm_layer(const LayerW32& L, int slice, int nslices, unsigned& acc) {
+    const int chunks = L.ntiles * L.ks * (CHUNK_BYTES / 16);
+    const int per = (chunks + nslices - 1) / nslices;
+    const int lo = slice * per, hi = min(chunks, lo + per);
+    const u32x4* p = reinterpret_cast<const u32x4*>(L.W);
+#pragma unroll 4
+    for (int i = lo + (int)threadIdx.x; i < hi; i += blockDim.x) {
+        const u32x4 v = p[i];
+        acc ^= v[0] ^ v[1] ^ v[2] ^ v[3];
+    }
+}
+
+// ---- arguments (mirrored in ops/hip.py; the layouts of csrc/fused.hip with fp32 pointers) --------
+struct CriticAhead32 {
+    int mode;        // 0: off; 1: only while the next batch is in the same chunk buffer; 2: always
+    int pad_;
+    float* h1;       // [B][ldh] relu(layer 1) row tiles (LDS images)
+    float* h2;       // [B][ldh]
+    float* lg;       // [B][nop] logits
+};
+struct ActorFwd32 {
+    LayerW32 af[3];        // online actor, forward
+    const float* s;        // [B, ldx_in] state unless the batch is packed
+    float* sT;             // stashes for the actor's weight gradients (stash32_off)
+    float* h1T;
+    float* h2T;
+    float* g_xin;          // [B][ldx]  s | pi(s) | 0   (LDS tile images, read back by the actor phase)
+    float* g_h1;           // [B][ldh]
+    float* g_h2;           // [B][ldh]
+};
+struct CriticPhaseArgs32 {
+    PhaseDims d;
+    const float* sa;       // [B, ldx_in]  state | action
+    const float* s2;       // [B, ldx_in]  next state
+    const float* reward;
+    const float* done;
+    const float* gamma;
+    const float* weights;  // may be null
+    PackedIn pk;
+    LayerW32 ta[3];        // target actor, forward
+    LayerW32 tc[3];        // target critic, forward
+    LayerW32 cf[3];        // online critic, forward
+    LayerW32 cb3, cb2;     // online critic, backward (transposed copies) of layers 3 and 2
+    float* saT;
+    float* h1T;
+    float* h2T;
+    float* dlT;
+    float* dh2T;
+    float* dh1T;
+    float* per_loss;
+    float* priority;
+    ActorFwd32 fwd;
+    CriticAhead32 ahead;
+};
+struct ActorPhaseArgs32 {
+    PhaseDims d;
+    const float* g_xin;
+    const float* g_h1;
+    const float* g_h2;
+    LayerW32 cf[3];          // online critic (already updated), forward
+    LayerW32 cb3, cb2, cb1;  // critic backward: layers 3, 2 and the action columns of layer 1
+    LayerW32 ab3, ab2;       // actor backward: layers 3 and 2
+    float* daT;
+    float* dh2T;
+    float* dh1T;
+    float* q_val;
+    TreeUpdateArgs tree;     // priority write-back in one extra workgroup (tree.n == 0: none)
+    PackedIn pk;
+    float* c_saT;            // the critic's stashes, written by the forward pass made ahead
+    float* c_h1T;
+    float* c_h2T;
+    CriticAhead32 ahead;
+};
+
+__host__ __device__ __forceinline__ bool critic_red_aliased(const PhaseDims& d) { return (NW32 - 1) * 64 <= d.ldh; }
+
+// ---- loss rows: one wave per row ------------------------------------------------------------------
+struct CriticRowsOut {
+    float* dlT;
+    float* per_loss;
+    float* priority;
+};
+template <int SL, int M>
+__device__ __forceinline__ void critic_rows(const PhaseDims& d, const CriticRowsOut a, int row0, int lane, int wave,
+                                            const float* lg_t, const float* lg_o, float* dlg, float* sp, const float* rs) {
+    for (int r = wave; r < M; r += NW32) {
+        const int b = row0 + r;
+        const float rew = rs[r], nd = rs[M + r], g = rs[2 * M + r], scale = rs[3 * M + r];
+        if (d.distributional) {
+            float lt[SL], lo[SL], m[SL], dl[SL];
+            float* scratch = sp + wave * ((d.NO + 63) & ~63);
+#pragma unroll
+            for (int s = 0; s < SL; ++s) {
+                const int j = lane + 64 * s;
+                lt[s] = j < d.NO ? lg_t[r * d.nop + j] : -INFINITY;
+                lo[s] = j < d.NO ? lg_o[r * d.nop + j] : -INFINITY;
+            }
+            const float loss = d4pg_critic_row<SL, false>(lt, lo, rew, nd, g, d.NO, d.v_min, d.v_max, d.use_ce, scratch,
+                                                          scratch, lane, m, dl);
+#pragma unroll
+            for (int s = 0; s < SL; ++s) {
+                const int j = lane + 64 * s;
+                if (j < d.NO) {
+                    const float v = dl[s] * scale;
+                    dlg[r * d.ldd + j] = v;
+                    a.dlT[stash32_off(j, b, d.Bp)] = v;
+                }
+            }
+            if (lane == 0) {
+                a.per_loss[b] = loss;
+                a.priority[b] = fabsf(loss) + 1e-4f;
+            }
+        } else if (lane == 0) {
+            float y = rew + nd * g * lg_t[r * d.nop];
+            y = fminf(d.max_value, fmaxf(d.min_value, y));
+            const float diff = lg_o[r * d.nop] - y;
+            const float l = diff * diff;
+            const float v = 2.f * diff * scale;
+            dlg[r * d.ldd] = v;
+            a.dlT[stash32_off(0, b, d.Bp)] = v;
+            a.per_loss[b] = l;
+            a.priority[b] = fabsf(l) + 1e-4f;
+        }
+    }
+}
+
+template <int SL, int M>
+__device__ __forceinline__ void actor_rows(const PhaseDims& d, float* q_val, int row0, int lane, int wave, const float* lg_o,
+                                           float* dlg) {
+    for (int r = wave; r < M; r += NW32) {
+        const int b = row0 + r;
+        if (d.distributional) {
+            float e[SL], dl[SL];
+#pragma unroll
+            for (int s = 0; s < SL; ++s) {
+                const int j = lane + 64 * s;
+                e[s] = j < d.NO ? lg_o[r * d.nop + j] : -INFINITY;
+            }
+            const float qv = d4pg_actor_row<SL, false>(e, d.NO, d.v_min, d.v_max, lane, dl);
+#pragma unroll
+            for (int s = 0; s < SL; ++s) {
+                const int j = lane + 64 * s;
+                if (j < d.NO) dlg[r * d.ldd + j] = dl[s] * d.inv_B;
+            }
+            if (lane == 0) q_val[b] = qv;
+        } else if (lane == 0) {
+            dlg[r * d.ldd] = -d.inv_B;
+            q_val[b] = lg_o[r * d.nop];
+        }
+    }
+}
+
+// ---- the online actor's forward pass, in extra workgroups of the critic phase launch --------------
+template <int MT, int KSH, int KSN>
+__device__ __forceinline__ void actor_forward_role(const CriticPhaseArgs32& a, int row0, char* smem) {
+    constexpr int M = 4 * MT;
+    const PhaseDims& d = a.d;
+    const ActorFwd32& f = a.fwd;
+    int off = 0;
+    auto carve = [&](int bytes) { char* p = smem + off; off += (bytes + 15) & ~15; return p; };
+    float* xin = (float*)carve(M * d.ldx * 4);     // [s | pi(s)]
+    float* bufA = (float*)carve(M * d.ldh * 4);    // h1
+    float* bufB = (float*)carve(M * d.ldh * 4);    // h2
+    float* red = (float*)carve((NW32 - 1) * MT * 256 * 4);
+    Chain32<MT, KSH, KSN> ch(red);
+    ch.template prefetch<0>(f.af[0]);
+    // (the epilogue lambdas capture scalars only: a closure that holds a copy of the kernel arguments
+    // sends all of them through scratch memory, which also makes every buffer descriptor look divergent)
+    const int ldh = d.ldh, ldx = d.ldx, Bp = d.Bp, S = d.S;
+    float* const h1T = f.h1T;
+    float* const h2T = f.h2T;
+    zero_tail(bufA, ldh, M, d.H);
+    zero_tail(bufB, ldh, M, d.H);
+    load_input(a.pk.enabled ? packed_src(a.pk, 0) : plain_src(f.s, d.ldx_in, d.B), row0, M, S, xin, ldx, f.sT, Bp);
+    __syncthreads();
+    ch.template narrow<0>(xin, ldx, f.af[0], [=](int r0, int col, f32x4 v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        put_lds4(bufA, ldh, r0, col, v);
+        put_stash4(h1T, Bp, col, row0 + r0, v);
+    }, [&] { ch.template prefetch<1>(f.af[1]); });
+    __syncthreads();
+    copy16(f.g_h1 + (size_t)row0 * ldh, bufA, M * ldh * 4);
+    ch.template hidden<1>(bufA, ldh, f.af[1], [=](int r0, int col, f32x4 v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        put_lds4(bufB, ldh, r0, col, v);
+        put_stash4(h2T, Bp, col, row0 + r0, v);
+    }, [&] { ch.template prefetch<0>(f.af[2]); });
+    __syncthreads();
+    copy16(f.g_h2 + (size_t)row0 * ldh, bufB, M * ldh * 4);
+    ch.template split<0>(bufB, ldh, f.af[2], [=](int r0, int col, f32x4 v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fast_tanh(v[r]);
+        put_lds4(xin, ldx, r0, S + col, v);
+    }, [] {});
+    __syncthreads();
+    copy16(f.g_xin + (size_t)row0 * d.ldx, xin, M * d.ldx * 4);
+}
+
+// Everything after the logits of both critics: loss rows, then dX through critic layers 3 and 2.
+template <int MT, int KSH, int KSN>
+__device__ __forceinline__ void critic_tail(const CriticPhaseArgs32& a, Chain32<MT, KSH, KSN>& ch, int row0, int lane,
+                                            int wave, const float* lg_t, const float* lg_o, float* dlg, float* sp,
+                                            const float* rs, float* bufC, float* bufD) {
+    constexpr int M = 4 * MT;
+    const PhaseDims& d = a.d;
+    __syncthreads();
+    critic_rows<1, M>(d, CriticRowsOut{a.dlT, a.per_loss, a.priority}, row0, lane, wave, lg_t, lg_o, dlg, sp, rs);
+    __syncthreads();
+    const int ldh = d.ldh, Bp = d.Bp;
+    float* const dh2T = a.dh2T;
+    float* const dh1T = a.dh1T;
+    ch.template narrow<1>(dlg, d.ldd, a.cb3, [=](int r0, int col, f32x4 v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = bufD[(r0 + r) * ldh + col] > 0.f ? v[r] : 0.f;
+        put_lds4(bufD, ldh, r0, col, v);       // in place: each element is read and written by one lane
+        put_stash4(dh2T, Bp, col, row0 + r0, v);
+    }, [&] { ch.template prefetch<0>(a.cb2); });
+    __syncthreads();
+    ch.template hidden<0>(bufD, ldh, a.cb2, [=](int r0, int col, f32x4 v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = bufC[(r0 + r) * ldh + col] > 0.f ? v[r] : 0.f;
+        put_stash4(dh1T, Bp, col, row0 + r0, v);
+    }, [] {});
+}
+
+template <int MT, int KSH, int KSN>
+__global__ __launch_bounds__(64 * NW32) void critic_phase32_kernel(const CriticPhaseArgs32 a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int M = 4 * MT;
+    const PhaseDims& d = a.d;
+    const int row0 = blockIdx.x * M;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (row0 >= 2 * d.B) {     // beyond both halves: L2 warmers
+        const int sl = (blockIdx.x - 2 * (d.B / M)) >> 3, nsl = (gridDim.x - 2 * (d.B / M) + 7) >> 3;
+        unsigned acc = 0;
+        warm_layer(a.ta[0], sl, nsl, acc);
+        warm_layer(a.fwd.af[0], sl, nsl, acc);
+        warm_layer(a.ta[1], sl, nsl, acc);
+        warm_layer(a.fwd.af[1], sl, nsl, acc);
+        warm_layer(a.ta[2], sl, nsl, acc);
+        warm_layer(a.fwd.af[2], sl, nsl, acc);
+        warm_layer(a.tc[0], sl, nsl, acc);
+        warm_layer(a.tc[1], sl, nsl, acc);
+        warm_layer(a.tc[2], sl, nsl, acc);
+        warm_layer(a.cf[0], sl, nsl, acc);
+        warm_layer(a.cf[1], sl, nsl, acc);
+        warm_layer(a.cf[2], sl, nsl, acc);
+        warm_layer(a.cb3, sl, nsl, acc);
+        warm_layer(a.cb2, sl, nsl, acc);
+        asm volatile("" ::"v"(acc));
+        return;
+    }
+    if (row0 >= d.B) {         // the second half of the grid: actor forward (+ the per-update tick)
+        if (a.pk.do_tick && row0 == d.B && threadIdx.x == 0)
+            devstate_tick(a.pk.st, a.pk.beta1, a.pk.beta2, a.pk.per_b0, a.pk.per_b1, a.pk.total_steps);
+        actor_forward_role<MT, KSH, KSN>(a, row0 - d.B, smem);
+        return;
+    }
+    int off = 0;
+    auto carve = [&](int bytes) { char* p = smem + off; off += (bytes + 15) & ~15; return p; };
+    float* xin = (float*)carve(M * d.ldx * 4);     // [s | a]
+    float* xin2 = (float*)carve(M * d.ldx * 4);    // [s' | a']
+    float* bufA = (float*)carve(M * d.ldh * 4);
+    float* bufB = (float*)carve(M * d.ldh * 4);
+    float* bufC = (float*)carve(M * d.ldh * 4);    // h1 of the online critic (mask for the backward)
+    float* bufD = (float*)carve(M * d.ldh * 4);    // h2 of the online critic, then dh2 in place
+    float* dlg = (float*)carve(M * d.ldd * 4);
+    float* lg_t = (float*)carve(M * d.nop * 4);
+    float* lg_o = (float*)carve(M * d.nop * 4);
+    float* sp = (float*)carve(NW32 * ((d.NO + 63) & ~63) * 4);     // per-wave projection rows
+    float* rs = (float*)carve(4 * M * 4);          // reward | 1 - done | gamma | weight / B
+    // The K-slice partial sums of the three output layers (a', target logits, logits) go where bufA is:
+    // its tile (an input of the hidden layer before) is dead whenever one of them runs.  Only when they
+    // fit; a 16-row tile of a 400-wide network needs every byte of the LDS.
+    float* red = critic_red_aliased(d) ? bufA : (float*)carve((NW32 - 1) * MT * 256 * 4);
+    Chain32<MT, KSH, KSN> ch(red);
+    ch.template prefetch<0>(a.ta[0]);
+    const int SA = d.S + d.A;
+    const RowSrc src_sa = a.pk.enabled ? packed_src(a.pk, 0) : plain_src(a.sa, d.ldx_in, d.B);
+    const RowSrc src_s2 = a.pk.enabled ? packed_src(a.pk, SA + 3) : plain_src(a.s2, d.ldx_in, d.B);
+    float rs_r = 0.f, rs_nd = 0.f, rs_g = 0.f, rs_w = 0.f;
+    if (threadIdx.x < M) {
+        const int b = row0 + threadIdx.x;
+        if (a.pk.enabled) {
+            const float* row = row_of(src_sa, b);
+            rs_r = row[SA];
+            rs_nd = 1.f - row[SA + 1];
+            rs_g = d.fixed_gamma >= 0.f ? d.fixed_gamma : row[SA + 2];
+            rs_w = row[a.pk.row_ld] * d.inv_B;
+        } else {
+            rs_r = a.reward[b];
+            rs_nd = 1.f - a.done[b];
+            rs_g = d.fixed_gamma >= 0.f ? d.fixed_gamma : a.gamma[b];
+            rs_w = (a.weights ? a.weights[b] : 1.f) * d.inv_B;
+        }
+    }
+    zero_block(dlg, M * d.ldd * 4);
+    zero_tail(bufA, d.ldh, M, d.H);
+    zero_tail(bufB, d.ldh, M, d.H);
+    // Was the online critic's forward pass on exactly these rows made ahead, after the last change of
+    // the critic weights?  (wave-uniform; CriticAhead in csrc/fused.hip)
+    bool ahead_ok = false;
+    if (a.ahead.mode != 0 && a.pk.enabled)
+        ahead_ok = a.pk.st->pad_[AHEAD_STEP] == a.pk.st->step_done + 1 &&
+                   a.pk.st->pad_[AHEAD_ROWS] == (long long)(uintptr_t)src_sa.base;
+    if (ahead_ok) {
+        copy16(bufC, a.ahead.h1 + (size_t)row0 * d.ldh, M * d.ldh * 4);
+        copy16(bufD, a.ahead.h2 + (size_t)row0 * d.ldh, M * d.ldh * 4);
+        copy16(lg_o, a.ahead.lg + (size_t)row0 * d.nop, M * d.nop * 4);
+    } else {
+        zero_tail(bufC, d.ldh, M, d.H);
+        zero_tail(bufD, d.ldh, M, d.H);
+        load_input(src_sa, row0, M, SA, xin, d.ldx, a.saT, d.Bp);
+    }
+    load_input(src_s2, row0, M, d.S, xin2, d.ldx, nullptr, 0);
+    if (threadIdx.x < M) {
+        rs[threadIdx.x] = rs_r;
+        rs[M + threadIdx.x] = rs_nd;
+        rs[2 * M + threadIdx.x] = rs_g;
+        rs[3 * M + threadIdx.x] = rs_w;
+    }
+    __syncthreads();
+
+    const int ldh = d.ldh, ldx = d.ldx, nop = d.nop, Bp = d.Bp, S = d.S;
+    float* const h1T = a.h1T;
+    float* const h2T = a.h2T;
+    auto relu_to = [&](float* buf) {
+        return [=](int r0, int col, f32x4 v) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            put_lds4(buf, ldh, r0, col, v);
+        };
+    };
+    // ---- target actor: s' -> a' (written into the action columns of xin2) ----
+    ch.template narrow<0>(xin2, d.ldx, a.ta[0], relu_to(bufA), [&] { ch.template prefetch<1>(a.ta[1]); });
+    __syncthreads();
+    ch.template hidden<1>(bufA, d.ldh, a.ta[1], relu_to(bufB), [&] { ch.template prefetch<0>(a.ta[2]); });
+    __syncthreads();
+    ch.template split<0>(bufB, d.ldh, a.ta[2], [=](int r0, int col, f32x4 v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fast_tanh(v[r]);
+        put_lds4(xin2, ldx, r0, S + col, v);
+    }, [&] { ch.template prefetch<1>(a.tc[0]); });
+    __syncthreads();
+    // ---- target critic: (s', a') -> logits_t ----
+    ch.template narrow<1>(xin2, d.ldx, a.tc[0], relu_to(bufA), [&] { ch.template prefetch<0>(a.tc[1]); });
+    __syncthreads();
+    ch.template hidden<0>(bufA, d.ldh, a.tc[1], relu_to(bufB), [&] { ch.template prefetch<1>(a.tc[2]); });
+    __syncthreads();
+    // With the online critic's tiles made ahead its three layers are skipped; the first of them is
+    // prefetched by the layer before, so skipping is expressed as a layer without tiles (every load of it
+    // out of range), with the fields selected one by one (see csrc/fused.hip).
+    LayerW32 after_tc = a.cf[0];
+    after_tc.ntiles = ahead_ok ? 0 : a.cf[0].ntiles;
+    ch.template split<1>(bufB, d.ldh, a.tc[2], [=](int r0, int col, f32x4 v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lg_t[(r0 + r) * nop + col] = v[r];
+    }, [&] { ch.template prefetch<0>(after_tc); });
+    if (!ahead_ok) {
+        // ---- online critic: (s, a) -> logits, activations stashed for wgrad ----
+        ch.template narrow<0>(xin, d.ldx, a.cf[0], [=](int r0, int col, f32x4 v) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            put_lds4(bufC, ldh, r0, col, v);
+            put_stash4(h1T, Bp, col, row0 + r0, v);
+        }, [&] { ch.template prefetch<1>(a.cf[1]); });
+        __syncthreads();
+        ch.template hidden<1>(bufC, d.ldh, a.cf[1], [=](int r0, int col, f32x4 v) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            put_lds4(bufD, ldh, r0, col, v);
+            put_stash4(h2T, Bp, col, row0 + r0, v);
+        }, [&] { ch.template prefetch<0>(a.cf[2]); });
+        __syncthreads();
+        ch.template split<0>(bufD, d.ldh, a.cf[2], [=](int r0, int col, f32x4 v) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lg_o[(r0 + r) * nop + col] = v[r];
+        }, [] {});
+    }
+    // No prefetched registers are live where the two paths join: the first backward layer is fetched
+    // here and lands while the loss rows are computed.
+    ch.template prefetch<1>(a.cb3);
+    critic_tail<MT, KSH, KSN>(a, ch, row0, lane, wave, lg_t, lg_o, dlg, sp, rs, bufC, bufD);
+}
+
+// ---- the online critic's forward pass for the NEXT update, in extra workgroups of the actor phase ----
+template <int MT, int KSH, int KSN>
+__device__ __forceinline__ void critic_ahead_role(const ActorPhaseArgs32& a, int row0, char* smem) {
+    constexpr int M = 4 * MT;
+    const PhaseDims& d = a.d;
+    const long long s_next = a.pk.st->step_done - a.pk.step0 + 1;
+    // mode 1: the next chunk buffer may still be receiving its rows (all-gather on another stream)
+    if (a.ahead.mode == 1 && s_next % a.pk.K == 0) return;
+    int off = 0;
+    auto carve = [&](int bytes) { char* p = smem + off; off += (bytes + 15) & ~15; return p; };
+    float* xin = (float*)carve(M * d.ldx * 4);
+    float* bufC = (float*)carve(M * d.ldh * 4);
+    float* bufD = (float*)carve(M * d.ldh * 4);
+    float* lg = (float*)carve(M * d.nop * 4);
+    float* red = (float*)carve((NW32 - 1) * MT * 256 * 4);
+    Chain32<MT, KSH, KSN> ch(red);
+    ch.template prefetch<0>(a.cf[0]);
+    zero_tail(bufC, d.ldh, M, d.H);
+    zero_tail(bufD, d.ldh, M, d.H);
+    const RowSrc src = packed_src(a.pk, 0, 1);
+    const int ldh = d.ldh, nop = d.nop, Bp = d.Bp;
+    float* const h1T = a.c_h1T;
+    float* const h2T = a.c_h2T;
+    load_input(src, row0, M, d.S + d.A, xin, d.ldx, a.c_saT, Bp);
+    __syncthreads();
+    ch.template narrow<0>(xin, d.ldx, a.cf[0], [=](int r0, int col, f32x4 v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        put_lds4(bufC, ldh, r0, col, v);
+        put_stash4(h1T, Bp, col, row0 + r0, v);
+    }, [&] { ch.template prefetch<1>(a.cf[1]); });
+    __syncthreads();
+    copy16(a.ahead.h1 + (size_t)row0 * ldh, bufC, M * ldh * 4);
+    ch.template hidden<1>(bufC, ldh, a.cf[1], [=](int r0, int col, f32x4 v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        put_lds4(bufD, ldh, r0, col, v);
+        put_stash4(h2T, Bp, col, row0 + r0, v);
+    }, [&] { ch.template prefetch<0>(a.cf[2]); });
+    __syncthreads();
+    copy16(a.ahead.h2 + (size_t)row0 * ldh, bufD, M * ldh * 4);
+    ch.template split<0>(bufD, ldh, a.cf[2], [=](int r0, int col, f32x4 v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lg[(r0 + r) * nop + col] = v[r];
+    }, [] {});
+    __syncthreads();
+    copy16(a.ahead.lg + (size_t)row0 * d.nop, lg, M * d.nop * 4);
+    if (row0 == 0 && threadIdx.x == 0) {     // the tag: which update and which rows these tiles are for
+        a.pk.st->pad_[AHEAD_STEP] = a.pk.st->step_done + 2;
+        a.pk.st->pad_[AHEAD_ROWS] = (long long)(uintptr_t)src.base;
+    }
+}
+
+template <int MT, int KSH, int KSN>
+__global__ __launch_bounds__(64 * NW32) void actor_phase32_kernel(const ActorPhaseArgs32 a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int M = 4 * MT;
+    const PhaseDims& d = a.d;
+    const int row0 = blockIdx.x * M;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n_tree = a.tree.n > 0 ? 1 : 0;
+    const int n_work = d.B / M + n_tree + (a.ahead.mode != 0 ? d.B / M : 0);
+    if ((int)blockIdx.x >= n_work) {                // L2 warmers
+        const int sl = (blockIdx.x - n_work) >> 3, nsl = (gridDim.x - n_work + 7) >> 3;
+        unsigned acc = 0;
+        warm_layer(a.cf[0], sl, nsl, acc);
+        warm_layer(a.cf[1], sl, nsl, acc);
+        warm_layer(a.cf[2], sl, nsl, acc);
+        warm_layer(a.cb3, sl, nsl, acc);
+        warm_layer(a.cb2, sl, nsl, acc);
+        warm_layer(a.cb1, sl, nsl, acc);
+        warm_layer(a.ab3, sl, nsl, acc);
+        warm_layer(a.ab2, sl, nsl, acc);
+        asm volatile("" ::"v"(acc));
+        return;
+    }
+    if ((int)blockIdx.x >= d.B / M + n_tree) {      // the online critic's forward pass of the next update
+        critic_ahead_role<MT, KSH, KSN>(a, (blockIdx.x - (d.B / M + n_tree)) * M, smem);
+        return;
+    }
+    if (row0 >= d.B) {         // the extra workgroup: priorities back into the tree
+        tree_update_body<NW32>(a.tree);
+        return;
+    }
+    int off = 0;
+    auto carve = [&](int bytes) { char* p = smem + off; off += (bytes + 15) & ~15; return p; };
+    float* xin = (float*)carve(M * d.ldx * 4);     // [s | pi(s)]
+    float* bufA = (float*)carve(M * d.ldh * 4);    // h1 actor
+    float* bufB = (float*)carve(M * d.ldh * 4);    // h2 actor, then dh2 actor in place
+    float* bufC = (float*)carve(M * d.ldh * 4);    // h1 critic, then dh1 critic in place
+    float* bufD = (float*)carve(M * d.ldh * 4);    // h2 critic, then dh2 critic in place
+    float* dlg = (float*)carve(M * d.ldd * 4);
+    float* dab = (float*)carve(M * d.lda_ * 4);
+    float* lg_o = (float*)carve(M * d.nop * 4);
+    float* red = (float*)carve((NW32 - 1) * MT * 256 * 4);
+    Chain32<MT, KSH, KSN> ch(red);
+    ch.template prefetch<0>(a.cf[0]);
+    // ---- the actor forward pass of this tile was made alongside the critic phase ----
+    copy16(xin, a.g_xin + (size_t)row0 * d.ldx, M * d.ldx * 4);
+    copy16(bufA, a.g_h1 + (size_t)row0 * d.ldh, M * d.ldh * 4);
+    copy16(bufB, a.g_h2 + (size_t)row0 * d.ldh, M * d.ldh * 4);
+    zero_block(dlg, M * (d.ldd + d.lda_) * 4);      // dlg and dab are adjacent
+    zero_tail(bufC, d.ldh, M, d.H);
+    zero_tail(bufD, d.ldh, M, d.H);
+    __syncthreads();
+    const int ldh = d.ldh, ldx = d.ldx, nop = d.nop, Bp = d.Bp, S = d.S, lda_ = d.lda_;
+    float* const daT = a.daT;
+    float* const dh2T = a.dh2T;
+    float* const dh1T = a.dh1T;
+    auto relu_to = [&](float* buf) {
+        return [=](int r0, int col, f32x4 v) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            put_lds4(buf, ldh, r0, col, v);
+        };
+    };
+    // ---- critic forward at (s, pi(s)) ----
+    ch.template narrow<0>(xin, d.ldx, a.cf[0], relu_to(bufC), [&] { ch.template prefetch<1>(a.cf[1]); });
+    __syncthreads();
+    ch.template hidden<1>(bufC, ldh, a.cf[1], relu_to(bufD), [&] { ch.template prefetch<0>(a.cf[2]); });
+    __syncthreads();
+    ch.template split<0>(bufD, ldh, a.cf[2], [=](int r0, int col, f32x4 v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lg_o[(r0 + r) * nop + col] = v[r];
+    }, [&] { ch.template prefetch<1>(a.cb3); });
+    __syncthreads();
+    // ---- actor loss: -mean Q ----
+    actor_rows<1, M>(d, a.q_val, row0, lane, wave, lg_o, dlg);
+    __syncthreads();
+    // ---- critic backward (dX only) down to the action ----
+    ch.template narrow<1>(dlg, d.ldd, a.cb3, [=](int r0, int col, f32x4 v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = bufD[(r0 + r) * ldh + col] > 0.f ? v[r] : 0.f;
+        put_lds4(bufD, ldh, r0, col, v);
+    }, [&] { ch.template prefetch<0>(a.cb2); });
+    __syncthreads();
+    ch.template hidden<0>(bufD, ldh, a.cb2, [=](int r0, int col, f32x4 v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = bufC[(r0 + r) * ldh + col] > 0.f ? v[r] : 0.f;
+        put_lds4(bufC, ldh, r0, col, v);
+    }, [&] { ch.template prefetch<1>(a.cb1); });
+    __syncthreads();
+    ch.template split<1>(bufC, ldh, a.cb1, [=](int r0, int col, f32x4 v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float y = xin[(r0 + r) * ldx + S + col];      // pi(s): d tanh = 1 - y^2
+            v[r] *= (1.f - y * y);
+        }
+        put_lds4(dab, lda_, r0, col, v);
+        put_stash4(daT, Bp, col, row0 + r0, v);
+    }, [&] { ch.template prefetch<0>(a.ab3); });
+    __syncthreads();
+    // ---- actor backward ----
+    ch.template narrow<0>(dab, lda_, a.ab3, [=](int r0, int col, f32x4 v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = bufB[(r0 + r) * ldh + col] > 0.f ? v[r] : 0.f;
+        put_lds4(bufB, ldh, r0, col, v);
+        put_stash4(dh2T, Bp, col, row0 + r0, v);
+    }, [&] { ch.template prefetch<1>(a.ab2); });
+    __syncthreads();
+    ch.template hidden<1>(bufB, ldh, a.ab2, [=](int r0, int col, f32x4 v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = bufA[(r0 + r) * ldh + col] > 0.f ? v[r] : 0.f;
+        put_stash4(dh1T, Bp, col, row0 + r0, v);
+    }, [] {});
+}
+
+// ---- host launchers -----------------------------------------------------------------------------
+static int lds_bytes_critic32(const PhaseDims& d, int M, int mt) {
+    auto al = [](int b) { return (b + 15) & ~15; };
+    return 2 * al(M * d.ldx * 4) + 4 * al(M * d.ldh * 4) + al(M * d.ldd * 4) + 2 * al(M * d.nop * 4) +
+           al(NW32 * ((d.NO + 63) & ~63) * 4) + al(4 * M * 4) + (critic_red_aliased(d) ? 0 : al((NW32 - 1) * mt * 256 * 4));
+}
+static int lds_bytes_actor32(const PhaseDims& d, int M, int mt) {
+    auto al = [](int b) { return (b + 15) & ~15; };
+    return al(M * d.ldx * 4) + 4 * al(M * d.ldh * 4) + al(M * d.ldd * 4) + al(M * d.lda_ * 4) + al(M * d.nop * 4) +
+           al((NW32 - 1) * mt * 256 * 4);
+}
+
+#define D4PG_PHASE32_LAUNCHER(NAME, KERNEL, ARGS)                                                         \
+    template <int KSH>                                                                                     \
+    int NAME(const ARGS* a, int mt, int ksn, int grid, int lds, hipStream_t stream) {                      \
+        if (mt == 1) {                                                                                     \
+            if (ksn <= 2) return launch_phase(KERNEL<1, KSH, 2>, *a, grid, NW32, lds, stream);             \
+            return launch_phase(KERNEL<1, KSH, 4>, *a, grid, NW32, lds, stream);                           \
+        }                                                                                                  \
+        if (mt == 2) {                                                                                     \
+            if (ksn <= 2) return launch_phase(KERNEL<2, KSH, 2>, *a, grid, NW32, lds, stream);             \
+            return launch_phase(KERNEL<2, KSH, 4>, *a, grid, NW32, lds, stream);                           \
+        }                                                                                                  \
+        if (ksn <= 2) return launch_phase(KERNEL<4, KSH, 2>, *a, grid, NW32, lds, stream);                 \
+        return launch_phase(KERNEL<4, KSH, 4>, *a, grid, NW32, lds, stream);                               \
+    }
+D4PG_PHASE32_LAUNCHER(launch_critic32_ksh, critic_phase32_kernel, CriticPhaseArgs32)
+D4PG_PHASE32_LAUNCHER(launch_actor32_ksh, actor_phase32_kernel, ActorPhaseArgs32)
+
+#define D4PG_PHASE32_INSTANCES(PREFIX, KSHV)                                                                   \
+    PREFIX template int launch_critic32_ksh<KSHV>(const CriticPhaseArgs32*, int, int, int, int, hipStream_t);  \
+    PREFIX template int launch_actor32_ksh<KSHV>(const ActorPhaseArgs32*, int, int, int, int, hipStream_t);
+#if D4PG_KSH_PART == -1          // main unit: the widths live in their own objects
+D4PG_PHASE32_INSTANCES(extern, 13)
+D4PG_PHASE32_INSTANCES(extern, 4)
+D4PG_PHASE32_INSTANCES(extern, 8)
+#elif D4PG_KSH_PART != 99        // the unit of one width
+D4PG_PHASE32_INSTANCES(, D4PG_KSH_PART)
+#endif
+
+#if D4PG_MAIN_UNIT
+static int check_dims32(const PhaseDims& d, int M) {
+    if (d.B < M || d.B % M) return -1;
+    if (d.Bp < d.B || (d.Bp & 31)) return -2;
+    if ((d.ldx & 3) || (d.ldh & 3) || (d.ldd & 3) || (d.lda_ & 3)) return -3;
+    if (d.NO < 1 || d.NO > 64 || d.A > 64 || d.nop < d.NO || (d.nop & 3)) return -4;
+    if (d.ldx < d.S + d.A || d.ldx_in < d.S + d.A) return -5;
+    return 0;
+}
+// kind 0: N = hidden width, K = hidden width; 1: single column tile, K = hidden width in K-slices;
+// 2: K <= 32 * ksn, N = hidden width.  `ld` = floats readable per row of the LDS tile it multiplies.
+static int check_layer32(const LayerW32& L, int kind, int ksh, int ksn, int ld) {
+    if (L.W == nullptr || L.bias == nullptr || (((uintptr_t)L.W) & 15)) return -6;
+    if (L.ntiles < 1 || L.ntiles > NW32 || L.ksplit < 1 || L.ksplit > NW32 || L.nch < 1) return -6;
+    if (L.ks != L.nch * L.ksplit || L.N < 1 || L.N > 64 * L.ntiles || L.ks * 32 + LDS_PAD32 > ld) return -7;
+    if ((long long)L.ntiles * L.ks * CHUNK_BYTES >= (1ll << 31)) return -7;
+    if (kind == 0) return (L.ksplit == 1 && L.nch == ksh) ? 0 : -10;
+    if (kind == 1) return (L.ntiles == 1 && L.nch == split_nch(ksh) && L.ks >= ksh) ? 0 : -10;
+    return (L.ksplit == 1 && L.nch <= ksn) ? 0 : -10;
+}
+static int hidden_chunks(const PhaseDims& d) { return (d.H + 31) / 32; }
+static int max2i(int a, int b) { return a > b ? a : b; }
+
+// L2 warmer workgroups per phase launch, only while the grid leaves CUs idle (csrc/fused.hip, n_warmers)
+static int n_warmers32(const PhaseDims& d, int M) {
+    if (d.B / M > 64) return 0;
+    static const int n = [] {
+        const char* e = getenv("D4PG_L2_WARMERS");
+        const int v = e ? atoi(e) : 32;
+        return v < 0 ? 0 : (v > 256 ? 256 : (v + 7) & ~7);
+    }();
+    return n;
+}
+
+#define DISPATCH_PHASE32(LAUNCHER, LDSFN)                                                   \
+    const int lds = LDSFN(d, M, mt);                                                        \
+    const int grid = d.B / M + extra_blocks;                                                \
+    if (ksh == 13) return LAUNCHER<13>(a, mt, ksn, grid, lds, stream);                      \
+    if (ksh == 4) return LAUNCHER<4>(a, mt, ksn, grid, lds, stream);                        \
+    if (ksh == 8) return LAUNCHER<8>(a, mt, ksn, grid, lds, stream);                        \
+    return -10;
+
+D4PG_API int d4pg_critic_phase32(const CriticPhaseArgs32* a, int mt, hipStream_t stream) {
+    const PhaseDims& d = a->d;
+    if (mt != 1 && mt != 2 && mt != 4) return -9;
+    const int M = 4 * mt;
+    if (int rc = check_dims32(d, M)) return rc;
+    const int ksh = hidden_chunks(d);
+    const int ksn = max2i(max2i(a->ta[0].nch, a->tc[0].nch), max2i(max2i(a->cf[0].nch, a->cb3.nch), a->fwd.af[0].nch)) <= 2 ? 2 : 4;
+    const LayerW32* nets[4] = {a->ta, a->tc, a->cf, a->fwd.af};
+    for (int i = 0; i < 4; ++i) {
+        if (int rc = check_layer32(nets[i][0], 2, ksh, ksn, d.ldx)) return rc;
+        if (int rc = check_layer32(nets[i][1], 0, ksh, ksn, d.ldh)) return rc;
+        if (int rc = check_layer32(nets[i][2], 1, ksh, ksn, d.ldh)) return rc;
+    }
+    if (int rc = check_layer32(a->cb3, 2, ksh, ksn, d.ldd)) return rc;
+    if (int rc = check_layer32(a->cb2, 0, ksh, ksn, d.ldh)) return rc;
+    if (a->fwd.g_xin == nullptr || a->fwd.g_h1 == nullptr || a->fwd.g_h2 == nullptr || a->fwd.sT == nullptr ||
+        a->fwd.h1T == nullptr || a->fwd.h2T == nullptr)
+        return -14;
+    if (int prc = check_packed(a->pk, d)) return prc;
+    if (a->ahead.mode != 0 && (a->ahead.h1 == nullptr || a->ahead.h2 == nullptr || a->ahead.lg == nullptr)) return -15;
+    const int extra_blocks = d.B / M + n_warmers32(d, M);      // the actor forward pass rides along, then the L2 warmers
+    DISPATCH_PHASE32(launch_critic32_ksh, lds_bytes_critic32)
+}
+
+D4PG_API int d4pg_actor_phase32(const ActorPhaseArgs32* a, int mt, hipStream_t stream) {
+    const PhaseDims& d = a->d;
+    if (mt != 1 && mt != 2 && mt != 4) return -9;
+    const int M = 4 * mt;
+    if (int rc = check_dims32(d, M)) return rc;
+    const int ksh = hidden_chunks(d);
+    const int ksn = max2i(a->cf[0].nch, max2i(a->cb3.nch, a->ab3.nch)) <= 2 ? 2 : 4;
+    if (int rc = check_layer32(a->cf[0], 2, ksh, ksn, d.ldx)) return rc;
+    if (int rc = check_layer32(a->cf[1], 0, ksh, ksn, d.ldh)) return rc;
+    if (int rc = check_layer32(a->cf[2], 1, ksh, ksn, d.ldh)) return rc;
+    if (int rc = check_layer32(a->cb3, 2, ksh, ksn, d.ldd)) return rc;
+    if (int rc = check_layer32(a->cb2, 0, ksh, ksn, d.ldh)) return rc;
+    if (int rc = check_layer32(a->cb1, 1, ksh, ksn, d.ldh)) return rc;
+    if (int rc = check_layer32(a->ab3, 2, ksh, ksn, d.lda_)) return rc;
+    if (int rc = check_layer32(a->ab2, 0, ksh, ksn, d.ldh)) return rc;
+    if (a->g_xin == nullptr || a->g_h1 == nullptr || a->g_h2 == nullptr) return -14;
+    if (a->tree.n < 0 || (a->tree.n > 0 && (a->tree.idx == nullptr || a->tree.prio == nullptr || a->tree.t.L < 0 ||
+                                            a->tree.t.L > MAXL)))
+        return -11;
+    if (a->ahead.mode != 0) {
+        if (a->ahead.mode < 0 || a->ahead.mode > 2 || !a->pk.enabled) return -15;
+        if (a->ahead.h1 == nullptr || a->ahead.h2 == nullptr || a->ahead.lg == nullptr || a->c_saT == nullptr ||
+            a->c_h1T == nullptr || a->c_h2T == nullptr)
+            return -15;
+        if (int prc = check_packed(a->pk, d)) return prc;
+    }
+    const int n_ahead = a->ahead.mode != 0 ? d.B / M : 0;
+    const int extra_blocks = (a->tree.n > 0 ? 1 : 0) + n_ahead + n_warmers32(d, M);
+    DISPATCH_PHASE32(launch_actor32_ksh, lds_bytes_actor32)
+}
+
+D4PG_API int d4pg_phase32_lds_bytes(const PhaseDims* d, int mt, int actor) {
+    return actor ? lds_bytes_actor32(*d, 4 * mt, mt) : lds_bytes_critic32(*d, 4 * mt, mt);
+}
+D4PG_API int d4pg_phase32_waves() { return NW32; }
+D4PG_API int d4pg_sizeof_LayerW32() { return (int)sizeof(LayerW32); }
+D4PG_API int d4pg_sizeof_CriticPhaseArgs32() { return (int)sizeof(CriticPhaseArgs32); }
+D4PG_API int d4pg_sizeof_ActorPhaseArgs32() { return (int)sizeof(ActorPhaseArgs32); }
+
+// ---------------------------------------------------------------------------------------
+// Weight gradients:  dW[o][i] = sum_b dY[b][o] * X[b][i],  db[o] = sum_b dY[b][o]
+// All layers of a network in one launch, 32x32 tiles on v_mfma_f32_32x32x2_f32; NWV waves split the
+// batch and combine through LDS, then ALL of them finish the tile: Adam, Polyak and the refresh of
+// the packed fp32 copies (forward: packed32_off(o, i); transposed: packed32_off(i - c0, o)) when the
+// optimiser is fused, or the plain gradient otherwise.
+// ---------------------------------------------------------------------------------------
+struct WgradDesc32 {
+    const float* AT;    // dY stash (stash32_off), rowsA features x Bp batch rows
+    const float* BT;    // X stash, rowsB features x Bp batch rows
+    float* C;           // dW fp32 [M][ldc]
+    float* rowsum;      // db fp32 [M] or null
+    int M, N;
+    int rowsA, rowsB;
+    int ldc;
+    int tiles_m, tiles_n, tile_base;
+    long long w_off, b_off;        // offsets (floats) of W and bias in the flat parameter buffer
+    long long sf_off, sb_off;      // forward / transposed packed-copy offsets (floats), -1: none
+    int sf_ks, sb_ks, sb_c0, sb_c1;
+};
+struct WgradGroup32 {
+    WgradDesc32 p[3];
+    int count, total_tiles;
+    int Bp;
+    int pad_;
+    WgradAdam opt;
+    const SampleArgs* smp;     // prioritised replay: the next batch is drawn by extra workgroups (csrc/fused.hip)
+    int smp_rows;
+    int pad2_;
+};
+
+template <int NWV>
+__global__ __launch_bounds__(64 * NWV) void wgrad32_kernel(const WgradGroup32 g) {
+    extern __shared__ __attribute__((aligned(16))) float wg_smem[];
+    float* red = wg_smem;                      // [NWV][16 accumulator registers][64 lanes]
+    float* cs = wg_smem + NWV * 16 * 64;       // [NWV][32] partial row sums
+    const int total = g.total_tiles;
+    const int id = blockIdx.x;
+    if (id == total) {          // the extra workgroup of a finishing launch
+        wgrad_finish_role<NWV>(g.opt, cs);
+        return;
+    }
+    if (id > total) {           // the batch of the next update (SampleArgs): one wave per row
+        const SampleArgs& sa = *g.smp;
+        const int b = (id - total - 1) * NWV + (int)(threadIdx.x >> 6);
+        const long long size = sa.st->replay_size;
+        if (b < sa.B && size > 0) sample_row(sa, b, sa.st->step_cur, size, threadIdx.x & 63);
+        return;
+    }
+    const int xcd = id & 7, local = id >> 3;
+    const int q = total >> 3, rem = total & 7;
+    const int tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + local;
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < 3; ++i)
+        if (i < g.count && tile >= g.p[i].tile_base) p = i;
+    const WgradDesc32& d = g.p[p];
+    const int t = tile - d.tile_base;
+    const int tm = t / d.tiles_n, tn = t - tm * d.tiles_n;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const bool m_ok = tm * 32 + r < d.M, n_ok = tn * 32 + r < d.N;
+    const int groups = g.Bp >> 3;              // groups of 8 batch rows: one 16-byte load per operand = 4 MFMAs
+    const float* arow = d.AT + ((size_t)tm * groups * 64 + lane) * 4;
+    const float* brow = d.BT + ((size_t)tn * groups * 64 + lane) * 4;
+    constexpr int EPT = 16 / NWV;              // accumulator registers (rows of column pn) finished per wave
+    const WgradAdam& o = g.opt;
+    const bool fuse = o.p != nullptr;
+    const int pn = tn * 32 + r;
+    auto row_of_reg = [&](int q) { return tm * 32 + 8 * (q >> 2) + 4 * h + (q & 3); };
+    AdamState ast[EPT];
+    float step_size = 0.f, inv_sqrt_bc2 = 0.f;
+    if (fuse) {
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            const int pm = row_of_reg(wave * EPT + i);
+            if (pm < d.M && pn < d.N) ast[i] = adam_fetch(o, d.w_off + (long long)pm * d.ldc + pn);
+        }
+        step_size = o.st->bc1;
+        inv_sqrt_bc2 = o.st->bc2;
+    }
+    const int per = (groups + NWV - 1) / NWV;
+    const int g0 = wave * per, g1 = min(groups, g0 + per);
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float asum = 0.f;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const bool want_rowsum = d.rowsum != nullptr && tn == 0;
+#pragma unroll 4
+    for (int gi = g0; gi < g1; ++gi) {
+        f32x4 av = *reinterpret_cast<const f32x4*>(arow + gi * 256);
+        f32x4 bv = *reinterpret_cast<const f32x4*>(brow + gi * 256);
+        av = m_ok ? av : zero;
+        bv = n_ok ? bv : zero;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
+        if (want_rowsum) asum += (av[0] + av[1]) + (av[2] + av[3]);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[(wave * 16 + i) * 64 + lane] = acc[i];
+    if (want_rowsum) {
+        asum += __shfl_xor(asum, 32, 64);
+        if (lane < 32) cs[wave * 32 + lane] = asum;
+    }
+    __syncthreads();
+    if (fuse) {
+        step_size = o.lr / step_size;
+        inv_sqrt_bc2 = 1.f / sqrtf(inv_sqrt_bc2);
+    }
+    const int cn = pn;
+    float* ps = (float*)o.p_shadow;
+    float* ts = (float*)o.t_shadow;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int reg = wave * EPT + i;
+        float gv = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) gv += red[(w * 16 + reg) * 64 + lane];
+        const int cm = row_of_reg(reg);
+        if (cm < d.M && cn < d.N) {
+            if (!fuse) {
+                d.C[(size_t)cm * d.ldc + cn] = gv;       // read by the gradient all-reduce
+            } else {
+                float tv;
+                const float pv = adam_apply(o, d.w_off + (long long)cm * d.ldc + cn, ast[i], gv, step_size, inv_sqrt_bc2, tv);
+                if (d.sf_off >= 0) {
+                    const long long so = d.sf_off + packed32_off(cm, cn, d.sf_ks);
+                    ps[so] = pv;
+                    ts[so] = tv;
+                }
+                if (d.sb_off >= 0 && cn >= d.sb_c0 && cn < d.sb_c1)
+                    ps[d.sb_off + packed32_off(cn - d.sb_c0, cm, d.sb_ks)] = pv;
+            }
+        }
+    }
+    if (d.rowsum != nullptr && tn == 0 && threadIdx.x < 32) {
+        const int cm = tm * 32 + threadIdx.x;
+        if (cm < d.M) {
+            float gb = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWV; ++w) gb += cs[w * 32 + threadIdx.x];
+            if (!fuse) d.rowsum[cm] = gb;
+            if (fuse) {
+                float tv;
+                adam_elem(o, d.b_off + cm, gb, step_size, inv_sqrt_bc2, tv);
+            }
+        }
+    }
+}
+
+template <typename K>
+static int launch_wgrad32(K kernel, int nwv, int grid, const WgradGroup32& g, hipStream_t stream) {
+    const int lds = nwv * (16 * 64 + 32) * 4;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    int extra = (g.opt.p != nullptr && g.opt.finish_step) ? 1 : 0;       // wgrad_finish_role
+    if (g.smp != nullptr) {
+        if (!extra || g.smp_rows < 1) return -5;
+        extra += (g.smp_rows + nwv - 1) / nwv;
+    }
+    hipLaunchKernelGGL(kernel, dim3(grid + extra), dim3(64 * nwv), lds, stream, g);
+    return (int)hipGetLastError();
+}
+
+D4PG_API int d4pg_wgrad32(WgradGroup32* g, hipStream_t stream) {
+    if (g->count < 1 || g->count > 3 || g->Bp < 32 || (g->Bp & 31)) return -1;
+    int base = 0;
+    for (int i = 0; i < g->count; ++i) {
+        WgradDesc32& d = g->p[i];
+        if (d.M < 1 || d.N < 1 || d.ldc < d.N) return -2;
+        if ((d.rowsA & 31) || (d.rowsB & 31) || d.rowsA < d.M || d.rowsB < d.N) return -2;
+        if (d.AT == nullptr || d.BT == nullptr || d.C == nullptr) return -3;
+        if ((((uintptr_t)d.AT) | ((uintptr_t)d.BT)) & 15) return -4;
+        d.tiles_m = (d.M + 31) / 32;
+        d.tiles_n = (d.N + 31) / 32;
+        d.tile_base = base;
+        base += d.tiles_m * d.tiles_n;
+    }
+    g->total_tiles = base;
+    int nwv = g->Bp >= 128 ? 16 : (g->Bp >= 64 ? 8 : 4);     // one group of 8 batch rows per wave up to 16 waves
+    if (const char* e = getenv("D4PG_WGRAD_WAVES")) nwv = atoi(e);
+    if (nwv == 16) return launch_wgrad32(wgrad32_kernel<16>, 16, base, *g, stream);
+    if (nwv == 8) return launch_wgrad32(wgrad32_kernel<8>, 8, base, *g, stream);
+    return launch_wgrad32(wgrad32_kernel<4>, 4, base, *g, stream);
+}
+D4PG_API int d4pg_sizeof_WgradGroup32() { return (int)sizeof(WgradGroup32); }
+#endif   // D4PG_MAIN_UNIT

@@ -12,12 +12,15 @@
 //  tick_kernel        : advances the device step counter and bias corrections when the
 //                       update is driven without the replay-sampling kernel.
 #include "common.h"
+#include "mlp32_dev.h"
 
 // bf16 "shadow" copies of the weight matrices for the fused bf16 pipeline (csrc/fused.hip).
 // The optimiser kernel refreshes them in the same pass that updates the fp32 masters:
 //   forward shadow   Wf(n = o, k = i)        rows padded to 16, K padded to 32 (B operand of y = x W^T)
 //   backward shadow  Wb(n = i - c0, k = o)   the transpose of input columns [c0, c1) (B operand of dX = dY W)
 // both stored in the packed fragment order of common.h (packed_off).  Pads are zero and never written.
+// The fused fp32 pipeline (csrc/fused32.hip) keeps the same two copies in fp32, in the fragment order of
+// csrc/mlp32_dev.h (packed32_off); ShadowArgs::f32 selects it (f_ld / b_ld = the padded K either way).
 struct ShadowMat {
     long long w_off;     // offset (floats) of W inside the range handed to the kernel
     long long f_off;     // forward shadow offset (bf16 elements), -1: none
@@ -27,11 +30,11 @@ struct ShadowMat {
     int pad_;
 };
 struct ShadowArgs {
-    __bf16* p_shadow;    // shadows of the online parameters (forward + backward)
-    __bf16* t_shadow;    // shadows of the target parameters (forward only), may be null
+    void* p_shadow;      // shadows of the online parameters (forward + backward): bf16, or fp32 when f32 != 0
+    void* t_shadow;      // shadows of the target parameters (forward only), may be null
     ShadowMat m[3];
-    int count;           // 0: no shadows (fp32 pipeline)
-    int pad_;
+    int count;           // 0: no shadows (one-launch-per-layer fp32 pipeline)
+    int f32;
 };
 
 struct AdamPolyakArgs {
@@ -67,13 +70,24 @@ __device__ __forceinline__ void write_shadows(const ShadowArgs& sh, long long e,
         for (int k = 0; k < 4; ++k) {
             const int i = i0 + k;
             if (i >= m.in_dim) continue;
+            if (sh.f32) {
+                float* ps = (float*)sh.p_shadow;
+                if (m.f_off >= 0) {
+                    const long long so = m.f_off + packed32_off(o, i, m.f_ld >> 5);
+                    ps[so] = p[k];
+                    if (sh.t_shadow != nullptr && t != nullptr) ((float*)sh.t_shadow)[so] = (*t)[k];
+                }
+                if (m.b_off >= 0 && i >= m.b_c0 && i < m.b_c1) ps[m.b_off + packed32_off(i - m.b_c0, o, m.b_ld >> 5)] = p[k];
+                continue;
+            }
+            __bf16* ps = (__bf16*)sh.p_shadow;
             if (m.f_off >= 0) {
                 const long long so = m.f_off + packed_off(o, i, m.f_ld >> 5);
-                sh.p_shadow[so] = (__bf16)p[k];
-                if (sh.t_shadow != nullptr && t != nullptr) sh.t_shadow[so] = (__bf16)(*t)[k];
+                ps[so] = (__bf16)p[k];
+                if (sh.t_shadow != nullptr && t != nullptr) ((__bf16*)sh.t_shadow)[so] = (__bf16)(*t)[k];
             }
             if (m.b_off >= 0 && i >= m.b_c0 && i < m.b_c1)
-                sh.p_shadow[m.b_off + packed_off(i - m.b_c0, o, m.b_ld >> 5)] = (__bf16)p[k];
+                ps[m.b_off + packed_off(i - m.b_c0, o, m.b_ld >> 5)] = (__bf16)p[k];
         }
         break;
     }

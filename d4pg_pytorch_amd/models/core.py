@@ -233,14 +233,17 @@ def build_core(cfg: Dict, device=None, seed: Optional[int] = None) -> CoreBase:
     device = torch.device(device if device is not None else cfg["device"])
     want = cfg.get("fused_learner", "auto")
     if device.type == "cuda" and want != "torch":
+        # fp32 (reference precision, models/d4pg/d4pg.py:73-77) is what "auto" means; bf16 MFMA operands are opt-in
         dtype = cfg.get("compute_dtype", "auto")
-        if dtype in ("bf16", "auto"):
-            from .hip_core_bf16 import HipCoreBf16
+        from .hip_core_bf16 import HipCoreBf16, ShapeLimit
+        if dtype == "bf16":
+            return HipCoreBf16(cfg, device, seed)
+        if cfg.get("fused_learner", "auto") != "layers":
+            from .hip_core_f32 import HipCoreF32
             try:
-                return HipCoreBf16(cfg, device, seed)
-            except ValueError:            # shape outside the fused pipeline's limits (batch % 16, LDS per workgroup)
-                if dtype == "bf16":
-                    raise
+                return HipCoreF32(cfg, device, seed)
+            except ShapeLimit:            # outside the fused pipeline's limits: one launch per layer, any shape
+                pass
         from .hip_core import HipCore
         return HipCore(cfg, device, seed)
     return TorchCore(cfg, device, seed)

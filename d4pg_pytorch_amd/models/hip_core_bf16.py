@@ -35,13 +35,23 @@ LDS_PAD = 8
 LDS_LIMIT = 160 * 1024
 
 
+class ShapeLimit(ValueError):
+    """The configuration is outside what a fused pipeline was built for (the caller falls back)."""
+
+
 class HipCoreBf16(HipCore):
+    # what differs between the fused pipelines of the two precisions (models/hip_core_f32.py)
+    _critic_args_cls = H.CriticPhaseArgs
+    _actor_args_cls = H.ActorPhaseArgs
+    _fn_critic, _fn_actor = "d4pg_critic_phase", "d4pg_actor_phase"
+    rows_per_tile_unit = 16          # a phase workgroup owns rows_per_tile_unit * mt batch rows
+
     def __init__(self, cfg: Dict, device="cuda", seed: Optional[int] = None):
         super().__init__(cfg, device, seed)
         lay, dev = self.layout, self.device
         B, S, A, Hd, NO = self.B, self.S, self.A, self.Hd, self.NO
         if B % 16:
-            raise ValueError("the fused bf16 pipeline needs batch_size to be a multiple of 16")
+            raise ShapeLimit("the fused bf16 pipeline needs batch_size to be a multiple of 16")
         self.sl = ShadowLayout.build(lay)
         self.shadow_online = torch.zeros(self.sl.numel, dtype=torch.bfloat16, device=dev)
         self.shadow_target = torch.zeros(self.sl.numel, dtype=torch.bfloat16, device=dev)
@@ -80,7 +90,7 @@ class HipCoreBf16(HipCore):
         need = max(H.lib().d4pg_phase_lds_bytes(self.dims, self.mt, 0),
                    H.lib().d4pg_phase_lds_bytes(self.dims, self.mt, 1))
         if need > LDS_LIMIT:
-            raise ValueError(f"dense_size={Hd} needs {need} bytes of LDS per workgroup (> {LDS_LIMIT}); "
+            raise ShapeLimit(f"dense_size={Hd} needs {need} bytes of LDS per workgroup (> {LDS_LIMIT}); "
                              f"use compute_dtype: fp32")
         self.refresh_shadows()
 
@@ -105,7 +115,7 @@ class HipCoreBf16(HipCore):
         self.packed_direct[name] = pk
         # moving the pass to the other launch only pays while that launch leaves compute units idle
         # (batch 4096: 93.9 us per update without, 98.6 us with)
-        fits = self.B // (16 * self.mt) <= 128
+        fits = self.B // (self.rows_per_tile_unit * self.mt) <= 128
         self.direct_ahead[name] = int(critic_ahead) if fits and int(os.environ.get("D4PG_CRITIC_AHEAD", "1")) else 0
         self.packed_unpack.pop(name, None)
         self._graphs = {k: v for k, v in self._graphs.items() if not k.startswith(name)}
@@ -317,7 +327,7 @@ class HipCoreBf16(HipCore):
                                            int(cfg["num_steps_train"]), H.stream_ptr()), "d4pg_tick")
             elif source in self.packed_unpack:      # a registered packed batch buffer: unpack it (this also ticks)
                 H.launch("d4pg_batch_unpack", self.packed_unpack[source])
-            a = H.CriticPhaseArgs()
+            a = self._critic_args_cls()
             a.d = dims
             if source in self.packed_direct:        # rows are read in place; the kernel ticks
                 a.pk = self.packed_direct[source]
@@ -345,12 +355,13 @@ class HipCoreBf16(HipCore):
                 f.af[i] = self._lw(SP, sl.actor[i], P, al[i])
             f.s = self.s_pi.data_ptr()
             f.sT, f.h1T, f.h2T = self.sT.data_ptr(), self.a_h1T.data_ptr(), self.a_h2T.data_ptr()
-            f.g_xin, f.g_h1, f.g_h2, f.g_pi = (self.g_xin.data_ptr(), self.g_h1.data_ptr(), self.g_h2.data_ptr(),
-                                               self.g_pi.data_ptr())
+            f.g_xin, f.g_h1, f.g_h2 = self.g_xin.data_ptr(), self.g_h1.data_ptr(), self.g_h2.data_ptr()
+            if self.g_pi is not None:
+                f.g_pi = self.g_pi.data_ptr()
             ah = a.ahead
             ah.mode = self.direct_ahead.get(source, 0)
             ah.h1, ah.h2, ah.lg = self.gc_h1.data_ptr(), self.gc_h2.data_ptr(), self.gc_lg.data_ptr()
-            H._check(H.lib().d4pg_critic_phase(a, self.mt, H.stream_ptr()), "d4pg_critic_phase")
+            H._check(getattr(H.lib(), self._fn_critic)(a, self.mt, H.stream_ptr()), self._fn_critic)
             # the priority write-back rides along with the actor phase (seg_actor)
             self._wgrad([(self.c_dlT, self.c_h2T, cl[2], sl.critic[2]), (self.c_dh2T, self.c_h1T, cl[1], sl.critic[1]),
                          (self.c_dh1T, self.saT, cl[0], sl.critic[0])],
@@ -359,10 +370,11 @@ class HipCoreBf16(HipCore):
         def seg_actor() -> None:
             if not fuse_opt:
                 H.launch("d4pg_adam_polyak", adam_args(lay.critic, sl.critic, self.lr_critic, 0))
-            a = H.ActorPhaseArgs()
+            a = self._actor_args_cls()
             a.d = dims
-            a.g_xin, a.g_h1, a.g_h2, a.g_pi = (self.g_xin.data_ptr(), self.g_h1.data_ptr(), self.g_h2.data_ptr(),
-                                               self.g_pi.data_ptr())
+            a.g_xin, a.g_h1, a.g_h2 = self.g_xin.data_ptr(), self.g_h1.data_ptr(), self.g_h2.data_ptr()
+            if self.g_pi is not None:
+                a.g_pi = self.g_pi.data_ptr()
             for i in range(3):
                 a.cf[i] = self._lw(SP, sl.critic[i], P, cl[i])
             a.cb3 = self._lw(SP, sl.critic[2], P, cl[2], back=True)
@@ -382,7 +394,7 @@ class HipCoreBf16(HipCore):
                 ah = a.ahead
                 ah.mode = self.direct_ahead[source]
                 ah.h1, ah.h2, ah.lg = self.gc_h1.data_ptr(), self.gc_h2.data_ptr(), self.gc_lg.data_ptr()
-            H._check(H.lib().d4pg_actor_phase(a, self.mt, H.stream_ptr()), "d4pg_actor_phase")
+            H._check(getattr(H.lib(), self._fn_actor)(a, self.mt, H.stream_ptr()), self._fn_actor)
             self._wgrad([(self.a_daT, self.a_h2T, al[2], sl.actor[2]), (self.a_dh2T, self.a_h1T, al[1], sl.actor[1]),
                          (self.a_dh1T, self.sT, al[0], sl.actor[0])],
                         opt=(self.lr_actor, True) if fuse_opt else None, sample_next=per_role)

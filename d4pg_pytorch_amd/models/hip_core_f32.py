@@ -1,0 +1,167 @@
+"""Fused row-local learner update in reference precision (``compute_dtype: fp32``, the default).
+
+The reference computes in fp32 end to end (``models/d4pg/d4pg.py:73-77`` ``.float()``,
+``models/d4pg/networks.py:23-25``).  This core keeps that precision — every product is an exact
+f32 multiply-add on the matrix cores — and the launch structure of :class:`HipCoreBf16`:
+
+====  ===================================================================
+ 1    critic_phase32  target actor -> target critic -> critic -> loss -> dX, per tile of 4/8/16 rows
+                      (+ the online actor's forward pass in extra workgroups)
+ 2    wgrad32         dW/db of the three critic layers + Adam + Polyak + packed-copy refresh
+ 3    actor_phase32   critic(s, pi(s)) -> expected Q -> dX critic -> dX actor
+                      (+ the critic's forward pass for the NEXT batch, + the PER tree update)
+ 4    wgrad32         the same for the actor; publishes the step
+====  ===================================================================
+
+``csrc/fused32.hip`` / ``csrc/mlp32_dev.h``: ``v_mfma_f32_4x4x1_16b_f32`` on 4-row tiles in the phases,
+``v_mfma_f32_32x32x2_f32`` in the weight gradients; weights are read from fp32 copies packed in
+fragment order (``Shadow32Layout``), which the optimiser inside ``wgrad32`` keeps current.
+Everything else (drawn-ahead batches read in place, 32 updates per graph replay, critic forward made
+ahead, prioritised draw riding in the last launch, checkpoints, data-parallel wiring) is inherited.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from ..ops import hip as H
+from .hip_core import HipCore
+from .hip_core_bf16 import LDS_LIMIT, HipCoreBf16, ShapeLimit
+from .nets import LayerSlot, Packed32, Shadow32Layout, Shadow32Slot, pad16, pad32, refresh_shadows32
+
+LDS_PAD32 = 4
+SUPPORTED_HIDDEN_CHUNKS = (4, 8, 13)      # phase kernels exist for hidden widths of 97..128, 225..256, 385..416
+
+
+class HipCoreF32(HipCoreBf16):
+    _critic_args_cls = H.CriticPhaseArgs32
+    _actor_args_cls = H.ActorPhaseArgs32
+    _fn_critic, _fn_actor = "d4pg_critic_phase32", "d4pg_actor_phase32"
+    rows_per_tile_unit = 4
+
+    def __init__(self, cfg: Dict, device="cuda", seed: Optional[int] = None):
+        HipCore.__init__(self, cfg, device, seed)
+        lay, dev = self.layout, self.device
+        B, S, A, Hd, NO = self.B, self.S, self.A, self.Hd, self.NO
+        waves = H.lib().d4pg_phase32_waves()
+        ksh = pad32(Hd) // 32
+        if ksh not in SUPPORTED_HIDDEN_CHUNKS or (Hd + 63) // 64 > waves:
+            raise ShapeLimit(f"dense_size={Hd}: the fused fp32 pipeline is built for hidden widths "
+                             f"{[f'{32 * k - 31}..{32 * k}' for k in SUPPORTED_HIDDEN_CHUNKS]}")
+        if NO > 64 or A > 64 or pad32(S + A) > 128 or pad32(NO) > 128:
+            raise ShapeLimit("the fused fp32 pipeline needs <= 64 atoms, <= 64 actions and state + action <= 128")
+        if B % 4:
+            raise ShapeLimit("the fused fp32 pipeline needs batch_size to be a multiple of 4")
+        self.sl = Shadow32Layout.build(lay, waves)
+        self.shadow_online = torch.zeros(self.sl.numel, dtype=torch.float32, device=dev)
+        self.shadow_target = torch.zeros(self.sl.numel, dtype=torch.float32, device=dev)
+        self.Bp = pad32(B)
+        self.zero_bias = torch.zeros(pad16(max(Hd, S + A, NO)), dtype=torch.float32, device=dev)
+
+        def stash(rows):          # fp32, operand-fragment order of the weight-gradient kernel (stash32_off)
+            return torch.zeros(pad32(rows), self.Bp, dtype=torch.float32, device=dev)
+        self.saT, self.c_h1T, self.c_h2T = stash(S + A), stash(Hd), stash(Hd)
+        self.c_dlT, self.c_dh2T, self.c_dh1T = stash(NO), stash(Hd), stash(Hd)
+        self.sT, self.a_h1T, self.a_h2T = stash(S), stash(Hd), stash(Hd)
+        self.a_daT, self.a_dh2T, self.a_dh1T = stash(A), stash(Hd), stash(Hd)
+        self.dims = self._phase_dims()
+        d = self.dims
+        self.g_xin = torch.zeros(B, d.ldx, dtype=torch.float32, device=dev)
+        self.g_h1 = torch.zeros(B, d.ldh, dtype=torch.float32, device=dev)
+        self.g_h2 = torch.zeros(B, d.ldh, dtype=torch.float32, device=dev)
+        self.g_pi = None          # pi(s) stays in the action columns of g_xin (fp32)
+        self.gc_h1 = torch.zeros(B, d.ldh, dtype=torch.float32, device=dev)
+        self.gc_h2 = torch.zeros(B, d.ldh, dtype=torch.float32, device=dev)
+        self.gc_lg = torch.zeros(B, d.nop, dtype=torch.float32, device=dev)
+        self.direct_ahead: Dict[str, int] = {}
+        # Rows per workgroup.  A layer costs the time to stream its weights through one CU whatever the tile
+        # height, until the MFMA work of the tile (2.3 us per 400 x 400 layer and 4 rows) exceeds it: 4-row
+        # tiles while their workgroups (critic + actor forward) fit the 256 CUs, taller tiles beyond.
+        want = str(cfg.get("phase_tile_rows", "auto"))
+        if want in ("4", "8", "16"):
+            self.mt = int(want) // 4
+        else:
+            self.mt = 1 if B // 4 <= 128 else (2 if B // 8 <= 128 else 4)
+        while self.mt > 1 and B % (4 * self.mt):
+            self.mt //= 2
+        need = max(H.lib().d4pg_phase32_lds_bytes(self.dims, self.mt, 0),
+                   H.lib().d4pg_phase32_lds_bytes(self.dims, self.mt, 1))
+        if need > LDS_LIMIT:
+            raise ShapeLimit(f"dense_size={Hd} needs {need} bytes of LDS per workgroup (> {LDS_LIMIT})")
+        self.refresh_shadows()
+
+    # ------------------------------------------------------------------ shadows
+    def refresh_shadows(self) -> None:
+        refresh_shadows32(self.online.flat.detach(), self.shadow_online, self.layout, self.sl)
+        refresh_shadows32(self.target.flat.detach(), self.shadow_target, self.layout, self.sl)
+        off = H.DevStateMirror.pad_.offset        # a critic forward pass made ahead is stale
+        self.dev_state[off:off + 16].zero_()
+
+    def _phase_dims(self) -> H.PhaseDims:
+        d = super()._phase_dims()
+        sl = self.sl
+        hidden_ks = max(sl.actor[1].f.ks, sl.actor[2].f.ks, sl.critic[2].f.ks, sl.critic[0].b.ks)
+        d.ldx = pad32(self.S + self.A) + LDS_PAD32
+        d.ldh = 32 * hidden_ks + LDS_PAD32        # K-sliced output layers pad K up to a multiple of the slices
+        d.ldd = pad32(self.NO) + LDS_PAD32
+        d.lda_ = pad32(self.A) + LDS_PAD32
+        d.nop = pad16(self.NO)
+        return d
+
+    # ------------------------------------------------------------- descriptors
+    def _lw(self, shadow: torch.Tensor, sh: Shadow32Slot, flat: torch.Tensor, slot: LayerSlot, back: bool = False) -> H.LayerW32:
+        L = H.LayerW32()
+        p: Packed32 = sh.b if back else sh.f
+        assert p is not None
+        L.W = shadow[p.off:].data_ptr()
+        L.bias = self.zero_bias.data_ptr() if back else flat[slot.b_off:].data_ptr()
+        L.ks, L.ntiles, L.N, L.ksplit, L.nch = p.ks, p.ntiles, p.N, p.ksplit, p.nch
+        return L
+
+    def _wgrad(self, triples, opt=None, sample_next: bool = False) -> None:
+        g = H.WgradGroup32()
+        for i, (dyT, xT, slot, sh) in enumerate(triples):
+            d = g.p[i]
+            d.AT, d.BT = dyT.data_ptr(), xT.data_ptr()
+            d.C = self.grad[slot.w_off:].data_ptr()
+            d.rowsum = self.grad[slot.b_off:].data_ptr()
+            d.M, d.N, d.rowsA, d.rowsB, d.ldc = slot.out_dim, slot.in_dim, dyT.shape[0], xT.shape[0], slot.ld
+            d.w_off, d.b_off = slot.w_off, slot.b_off
+            d.sf_off, d.sf_ks = sh.f.off, sh.f.ks
+            d.sb_off = sh.b.off if sh.b is not None else -1
+            d.sb_ks = sh.b.ks if sh.b is not None else 0
+            d.sb_c0, d.sb_c1 = sh.b_c0, sh.b_c1
+        g.count, g.Bp = len(triples), self.Bp
+        if opt is not None:
+            lr, finish = opt
+            o = g.opt
+            o.p, o.t = self.online.flat.data_ptr(), self.target.flat.data_ptr()
+            o.m, o.v = self.adam_m.data_ptr(), self.adam_v.data_ptr()
+            o.p_shadow, o.t_shadow = self.shadow_online.data_ptr(), self.shadow_target.data_ptr()
+            o.st = self.dev_state.data_ptr()
+            o.metrics = self.metrics.data_ptr() if finish else None
+            o.per_loss, o.weights, o.q_val = self.per_loss.data_ptr(), self.weights.data_ptr(), self.q_val.data_ptr()
+            o.B, o.inv_B = self.B, 1.0 / self.B
+            o.lr, o.beta1, o.beta2, o.eps, o.tau = lr, self.betas[0], self.betas[1], self.eps, self.tau
+            o.finish_step = 1 if finish else 0
+        if sample_next:
+            g.smp, g.smp_rows = self._smp_dev.data_ptr(), self.B
+        H._check(H.lib().d4pg_wgrad32(g, H.stream_ptr()), "d4pg_wgrad32")
+
+    def _shadow_args(self, net, slots, base: int) -> H.ShadowArgs:
+        """Packed-copy refresh inside the stand-alone optimiser kernel (gradient-exchange mode)."""
+        sa = H.ShadowArgs()
+        sa.p_shadow, sa.t_shadow = self.shadow_online.data_ptr(), self.shadow_target.data_ptr()
+        for i, (s, sh) in enumerate(zip(net.layers, slots)):
+            m = sa.m[i]
+            m.w_off = s.w_off - base
+            m.f_off = sh.f.off
+            m.b_off = sh.b.off if sh.b is not None else -1
+            m.out_dim, m.in_dim, m.ld = s.out_dim, s.in_dim, s.ld
+            m.f_ld = sh.f.ks * 32
+            m.b_ld = sh.b.ks * 32 if sh.b is not None else 0
+            m.b_c0, m.b_c1 = sh.b_c0, sh.b_c1
+        sa.count = 3
+        sa.f32 = 1
+        return sa

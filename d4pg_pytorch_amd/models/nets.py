@@ -317,3 +317,109 @@ def refresh_shadows(flat: torch.Tensor, shadow: torch.Tensor, lay: "LearnerLayou
                     b = torch.zeros(sh.b_rows, sh.b_ld, dtype=torch.bfloat16, device=shadow.device)
                     b[: sh.b_c1 - sh.b_c0, : s.out_dim] = W[:, sh.b_c0: sh.b_c1].t().to(torch.bfloat16)
                     shadow[sh.b_off: sh.b_off + sh.b_rows * sh.b_ld] = pack_fragments(b)
+
+
+# ---------------------------------------------------------------------------
+# packed fp32 weight copies for the fused fp32 pipeline (csrc/fused32.hip, csrc/mlp32_dev.h)
+# ---------------------------------------------------------------------------
+
+def pad64(n: int) -> int:
+    return (n + 63) // 64 * 64
+
+
+@dataclass(frozen=True)
+class Packed32:
+    """One B operand ``(N outputs, K)`` in fp32 fragment order ``[n/64][k/4][n%64][k%4]``
+    (``packed32_off`` in ``csrc/mlp32_dev.h``): ``ntiles`` column tiles of 64, ``ks`` chunks of 32 k.
+    ``ksplit`` > 1: a single-tile layer (N <= 64) whose K is dealt to the waves of a workgroup in
+    ``ksplit`` slices of ``nch`` chunks (``ks = nch * ksplit``, zero padded)."""
+    off: int
+    N: int
+    K: int
+    ntiles: int
+    ks: int
+    ksplit: int
+    nch: int
+
+    @property
+    def numel(self) -> int:
+        return self.ntiles * self.ks * 2048
+
+    @staticmethod
+    def geometry(N: int, K: int, split: bool, waves: int):
+        ntiles, ks = (N + 63) // 64, (K + 31) // 32
+        if split:
+            assert ntiles == 1
+            nch = (ks + waves - 1) // waves
+            ksplit = (ks + nch - 1) // nch
+            return ntiles, nch * ksplit, ksplit, nch
+        return ntiles, ks, 1, ks
+
+
+@dataclass(frozen=True)
+class Shadow32Slot:
+    """Packed fp32 copies of one weight matrix ``W[out, in]``: ``f`` = B operand of ``y = x W^T``
+    (n = out, k = in); ``b`` = B operand of ``dX = dY W`` restricted to input columns ``[c0, c1)``
+    (n = in - c0, k = out), or ``None``."""
+    f: Packed32
+    b: Optional[Packed32]
+    b_c0: int
+    b_c1: int
+
+
+@dataclass(frozen=True)
+class Shadow32Layout:
+    actor: Tuple[Shadow32Slot, Shadow32Slot, Shadow32Slot]
+    critic: Tuple[Shadow32Slot, Shadow32Slot, Shadow32Slot]
+    numel: int
+
+    @staticmethod
+    def build(lay: "LearnerLayout", waves: int) -> "Shadow32Layout":
+        off = 0
+
+        def packed(N, K, split):
+            nonlocal off
+            nt, ks, ksplit, nch = Packed32.geometry(N, K, split, waves)
+            p = Packed32(off, N, K, nt, ks, ksplit, nch)
+            off += p.numel
+            return p
+
+        def slot(s: LayerSlot, f_split: bool, back, b_split: bool = False):
+            f = packed(s.out_dim, s.in_dim, f_split)
+            if back is None:
+                return Shadow32Slot(f, None, 0, 0)
+            c0, c1 = back
+            return Shadow32Slot(f, packed(c1 - c0, s.out_dim, b_split), c0, c1)
+
+        a, c = lay.actor.layers, lay.critic.layers
+        S, A, Hd = lay.state_dim, lay.action_dim, lay.hidden
+        # output layers (N = actions / atoms <= 64, K = hidden) are dealt out in K-slices; so is the transpose
+        # of the action columns of critic layer 1, the only part of it that is ever back-propagated through
+        actor = (slot(a[0], False, None), slot(a[1], False, (0, Hd)), slot(a[2], True, (0, Hd)))
+        critic = (slot(c[0], False, (S, S + A), b_split=True), slot(c[1], False, (0, Hd)), slot(c[2], True, (0, Hd)))
+        return Shadow32Layout(actor, critic, off)
+
+
+def pack32(m: torch.Tensor, p: Packed32) -> torch.Tensor:
+    """``m[N, K]`` -> the flat packed copy described by ``p`` (zero padded)."""
+    full = torch.zeros(p.ntiles * 64, p.ks * 32, dtype=torch.float32, device=m.device)
+    full[: m.shape[0], : m.shape[1]] = m
+    return full.reshape(p.ntiles, 64, p.ks * 8, 4).permute(0, 2, 1, 3).reshape(-1)
+
+
+def unpack32(flat: torch.Tensor, p: Packed32) -> torch.Tensor:
+    """Inverse of :func:`pack32` (true rows / columns only)."""
+    return flat.reshape(p.ntiles, p.ks * 8, 64, 4).permute(0, 2, 1, 3).reshape(p.ntiles * 64, p.ks * 32)[: p.N, : p.K]
+
+
+def refresh_shadows32(flat: torch.Tensor, shadow: torch.Tensor, lay: "LearnerLayout", sl: Shadow32Layout) -> None:
+    """Rebuild every packed fp32 copy from the masters with torch ops (initialisation, checkpoint load,
+    parameter broadcast; the steady state is maintained by the optimiser kernels)."""
+    with torch.no_grad():
+        shadow.zero_()
+        for net, slots in ((lay.actor, sl.actor), (lay.critic, sl.critic)):
+            for s, sh in zip(net.layers, slots):
+                W = flat[s.w_off: s.w_off + s.w_numel].view(s.out_dim, s.ld)[:, : s.in_dim]
+                shadow[sh.f.off: sh.f.off + sh.f.numel] = pack32(W, sh.f)
+                if sh.b is not None:
+                    shadow[sh.b.off: sh.b.off + sh.b.numel] = pack32(W[:, sh.b_c0: sh.b_c1].t(), sh.b)

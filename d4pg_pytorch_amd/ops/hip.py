@@ -82,7 +82,7 @@ class ShadowMat(C.Structure):
 
 
 class ShadowArgs(C.Structure):
-    _fields_ = [("p_shadow", vp), ("t_shadow", vp), ("m", ShadowMat * 3), ("count", C.c_int), ("pad_", C.c_int)]
+    _fields_ = [("p_shadow", vp), ("t_shadow", vp), ("m", ShadowMat * 3), ("count", C.c_int), ("f32", C.c_int)]
 
 
 class AdamPolyakArgs(C.Structure):
@@ -219,6 +219,47 @@ class WgradGroup(C.Structure):
                 ("pad_", C.c_int), ("opt", WgradAdam), ("smp", vp), ("smp_rows", C.c_int), ("pad2_", C.c_int)]
 
 
+# ---- fused fp32 pipeline (csrc/fused32.hip) ----
+class LayerW32(C.Structure):
+    _fields_ = [("W", vp), ("bias", vp), ("ks", C.c_int), ("ntiles", C.c_int), ("N", C.c_int), ("ksplit", C.c_int),
+                ("nch", C.c_int), ("pad_", C.c_int)]
+
+
+class ActorFwd32(C.Structure):
+    _fields_ = [("af", LayerW32 * 3), ("s", vp), ("sT", vp), ("h1T", vp), ("h2T", vp),
+                ("g_xin", vp), ("g_h1", vp), ("g_h2", vp)]
+
+
+class CriticPhaseArgs32(C.Structure):
+    _fields_ = [("d", PhaseDims), ("sa", vp), ("s2", vp), ("reward", vp), ("done", vp), ("gamma", vp),
+                ("weights", vp), ("pk", PackedIn), ("ta", LayerW32 * 3), ("tc", LayerW32 * 3), ("cf", LayerW32 * 3),
+                ("cb3", LayerW32), ("cb2", LayerW32),
+                ("saT", vp), ("h1T", vp), ("h2T", vp), ("dlT", vp), ("dh2T", vp), ("dh1T", vp),
+                ("per_loss", vp), ("priority", vp), ("fwd", ActorFwd32), ("ahead", CriticAhead)]
+
+
+class ActorPhaseArgs32(C.Structure):
+    _fields_ = [("d", PhaseDims), ("g_xin", vp), ("g_h1", vp), ("g_h2", vp),
+                ("cf", LayerW32 * 3),
+                ("cb3", LayerW32), ("cb2", LayerW32), ("cb1", LayerW32), ("ab3", LayerW32), ("ab2", LayerW32),
+                ("daT", vp), ("dh2T", vp), ("dh1T", vp), ("q_val", vp),
+                ("tree", TreeUpdateArgs), ("pk", PackedIn), ("c_saT", vp), ("c_h1T", vp), ("c_h2T", vp),
+                ("ahead", CriticAhead)]
+
+
+class WgradDesc32(C.Structure):
+    _fields_ = [("AT", vp), ("BT", vp), ("C", vp), ("rowsum", vp), ("M", C.c_int), ("N", C.c_int),
+                ("rowsA", C.c_int), ("rowsB", C.c_int), ("ldc", C.c_int),
+                ("tiles_m", C.c_int), ("tiles_n", C.c_int), ("tile_base", C.c_int),
+                ("w_off", C.c_longlong), ("b_off", C.c_longlong), ("sf_off", C.c_longlong), ("sb_off", C.c_longlong),
+                ("sf_ks", C.c_int), ("sb_ks", C.c_int), ("sb_c0", C.c_int), ("sb_c1", C.c_int)]
+
+
+class WgradGroup32(C.Structure):
+    _fields_ = [("p", WgradDesc32 * 3), ("count", C.c_int), ("total_tiles", C.c_int), ("Bp", C.c_int),
+                ("pad_", C.c_int), ("opt", WgradAdam), ("smp", vp), ("smp_rows", C.c_int), ("pad2_", C.c_int)]
+
+
 class OuArgs(C.Structure):
     _fields_ = [("x", vp), ("action", vp), ("out", vp), ("sigma", vp), ("counter", vp), ("seed", C.c_ulonglong),
                 ("n", C.c_int), ("A", C.c_int), ("theta", C.c_float), ("mu", C.c_float), ("sigma_const", C.c_float),
@@ -234,6 +275,8 @@ class DevStateMirror(C.Structure):
                 ("seed", C.c_ulonglong), ("inserted_total", C.c_longlong),
                 ("pad_", C.c_longlong * 2)]
 
+
+_SIZE_CHECKED = (LayerW32, CriticPhaseArgs32, ActorPhaseArgs32, WgradGroup32)
 
 # ---------------------------------------------------------------------------
 # loader
@@ -278,6 +321,10 @@ def lib() -> C.CDLL:
             ("d4pg_phase_lds_bytes", [C.POINTER(PhaseDims), C.c_int, C.c_int]),
             ("d4pg_wgrad", [C.POINTER(WgradGroup), vp]),
             ("d4pg_ou_noise", [C.POINTER(OuArgs), vp]),
+            ("d4pg_critic_phase32", [C.POINTER(CriticPhaseArgs32), C.c_int, vp]),
+            ("d4pg_actor_phase32", [C.POINTER(ActorPhaseArgs32), C.c_int, vp]),
+            ("d4pg_phase32_lds_bytes", [C.POINTER(PhaseDims), C.c_int, C.c_int]),
+            ("d4pg_wgrad32", [C.POINTER(WgradGroup32), vp]),
         ):
             fn = getattr(_lib, name)
             fn.argtypes = argt
@@ -288,6 +335,14 @@ def lib() -> C.CDLL:
             raise RuntimeError("packed-batch layout mismatch between csrc/replay.hip and ops/hip.py")
         if _lib.d4pg_devstate_size() != C.sizeof(DevStateMirror):
             raise RuntimeError("DevState layout mismatch between csrc/common.h and ops/hip.py")
+        _lib.d4pg_phase32_waves.restype = C.c_int
+        # every argument struct mirrored above is checked against the size the kernels were compiled with:
+        # a drifted field would otherwise corrupt GPU memory silently
+        for cls in _SIZE_CHECKED:
+            fn = getattr(_lib, "d4pg_sizeof_" + cls.__name__)
+            fn.restype = C.c_int
+            if fn() != C.sizeof(cls):
+                raise RuntimeError(f"{cls.__name__}: {C.sizeof(cls)} bytes in ops/hip.py, {fn()} in csrc/")
     return _lib
 
 

@@ -77,10 +77,17 @@ def test_bf16_core_trains_like_fp32_and_keeps_shadows_in_sync(graph):
         hipc.update(b)
         torc.update(b)
     torch.cuda.synchronize()
-    # Adam normalises the step: after 10 steps parameters differ by at most ~10 * lr where signs flip
-    diff = (hipc.online.flat - torc.online.flat.detach()).abs()
-    assert diff.max().item() < 10 * 5e-4 * 2.1
-    assert diff.mean().item() < 5e-4
+    # Adam normalises the step, so the distance to the eager fp32 trajectory is measured in Adam steps
+    # (lr = 5e-4): a parameter whose gradient sign bf16 rounding flips drifts by up to 2 lr per update.
+    # Ten updates move a parameter by at most 10 lr; the bf16 pipeline must stay well inside that, on
+    # average and for all but 1 % of the parameters.
+    lr = cfg["critic_learning_rate"]
+    diff = (hipc.online.flat - torc.online.flat.detach()).abs() / lr
+    moved = (torc.online.flat.detach() - build_core(cfg, "cuda").online.flat).abs() / lr
+    print(f"bf16 vs eager after 10 updates, in Adam steps: mean {diff.mean().item():.3f}, "
+          f"p99 {diff.quantile(0.99).item():.3f}, max {diff.max().item():.3f}; eager moved mean {moved.mean().item():.3f}")
+    assert diff.mean().item() < 0.15 * moved.mean().item()
+    assert diff.quantile(0.99).item() < 2.0
     mh, mt = hipc.read_metrics(), torc.read_metrics()
     assert mh["count"] == 10
     assert abs(mh["value_loss"] - mt["value_loss"]) < 2e-2 * max(1.0, abs(mt["value_loss"]))
@@ -126,17 +133,3 @@ def test_bf16_update_from_replay_and_resume(per, tmp_path):
     core.update(b)
     other.update(b)
     torch.testing.assert_close(other.online.flat, core.online.flat, rtol=0, atol=0)
-
-
-def test_compute_dtype_auto_picks_the_fused_pipeline_where_it_fits():
-    """``compute_dtype: auto`` (the default): the bf16 pipeline when the batch is a multiple of 16,
-    the exact fp32 kernels otherwise; an explicit ``bf16`` with such a batch is an error."""
-    from d4pg_pytorch_amd.models.core import build_core
-    from d4pg_pytorch_amd.models.hip_core import HipCore
-    from d4pg_pytorch_amd.models.hip_core_bf16 import HipCoreBf16
-    assert default_config(env="Pendulum-v0")["compute_dtype"] == "auto"
-    assert isinstance(build_core(_cfg("d4pg", compute_dtype="auto"), "cuda"), HipCoreBf16)
-    odd = build_core(_cfg("d4pg", compute_dtype="auto", batch_size=40), "cuda")
-    assert isinstance(odd, HipCore) and not isinstance(odd, HipCoreBf16)
-    with pytest.raises(ValueError):
-        build_core(_cfg("d4pg", compute_dtype="bf16", batch_size=40), "cuda")

@@ -1,0 +1,174 @@
+"""Fused row-local fp32 pipeline (csrc/fused32.hip) against the eager fp32 torch oracle (GPU only).
+
+The reference computes in fp32 (``models/d4pg/d4pg.py:73-77``); this is the pipeline that runs by
+default, so the bounds are those of rounding, not of a reduced-precision format."""
+import numpy as np
+import pytest
+import torch
+
+from d4pg_pytorch_amd.config import default_config
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(model, **kw):
+    base = dict(env="LunarLanderContinuous-v2", model=model, batch_size=256, dense_size=400,
+                v_min=-20.0, v_max=20.0, device="cuda", num_steps_train=1000, random_seed=11)
+    base.update(kw)
+    return default_config(**base)
+
+
+def _batch(cfg, seed, device="cuda"):
+    from d4pg_pytorch_amd.models.core import Batch
+    g = torch.Generator().manual_seed(seed)
+    B, S, A = cfg["batch_size"], cfg["state_dim"], cfg["action_dim"]
+    return Batch(state=torch.randn(B, S, generator=g), action=torch.rand(B, A, generator=g) * 2 - 1,
+                 reward=torch.randn(B, generator=g), next_state=torch.randn(B, S, generator=g),
+                 done=(torch.rand(B, generator=g) < 0.1).float(),
+                 gamma=torch.full((B,), cfg["discount_rate"] ** cfg["n_step_returns"]),
+                 weights=torch.rand(B, generator=g) + 0.5, indices=torch.arange(B)).to(device)
+
+
+CASES = [("d4pg", {}), ("d4pg", {"critic_loss": "ce", "dense_size": 128}), ("d3pg", {}),
+         ("d4pg", {"env": "Ant-v2", "batch_size": 128, "use_per_sample_gamma": False}),       # 4 input chunks
+         ("ddpg", {"env": "Pendulum-v0", "dense_size": 100, "batch_size": 64}),
+         ("d4pg", {"env": "Walker2d-v2", "batch_size": 1024, "dense_size": 256}),             # 8-row tiles
+         ("d4pg", {"env": "BipedalWalker-v2", "batch_size": 2048}),                           # 16-row tiles
+         ("d4pg", {"batch_size": 36, "phase_tile_rows": "4"})]                                # batch not a multiple of 32
+
+
+def test_default_dtype_is_the_fused_fp32_pipeline():
+    """``compute_dtype: auto`` is reference precision; shapes outside the fused kernels fall back to the
+    per-layer fp32 kernels, never to bf16."""
+    from d4pg_pytorch_amd.models.core import build_core
+    from d4pg_pytorch_amd.models.hip_core import HipCore
+    from d4pg_pytorch_amd.models.hip_core_bf16 import HipCoreBf16
+    from d4pg_pytorch_amd.models.hip_core_f32 import HipCoreF32
+    assert default_config(env="Pendulum-v0")["compute_dtype"] == "auto"
+    assert isinstance(build_core(_cfg("d4pg"), "cuda"), HipCoreF32)
+    assert isinstance(build_core(_cfg("d4pg", compute_dtype="fp32"), "cuda"), HipCoreF32)
+    odd = build_core(_cfg("d4pg", dense_size=72), "cuda")
+    assert type(odd) is HipCore
+    assert type(build_core(_cfg("d4pg", fused_learner="layers"), "cuda")) is HipCore
+    bf = build_core(_cfg("d4pg", compute_dtype="bf16"), "cuda")
+    assert type(bf) is HipCoreBf16
+    with pytest.raises(ValueError):
+        build_core(_cfg("d4pg", compute_dtype="bf16", batch_size=40), "cuda")
+
+
+@pytest.mark.parametrize("model,kw", CASES)
+def test_f32_gradients_match_autograd(model, kw):
+    from d4pg_pytorch_amd.models.core import TorchCore, build_core
+    from d4pg_pytorch_amd.models.hip_core_f32 import HipCoreF32
+    cfg = _cfg(model, use_hip_graph=False, **kw)
+    hipc, torc = build_core(cfg, "cuda"), TorchCore(cfg, "cuda")
+    assert isinstance(hipc, HipCoreF32)
+    b = _batch(cfg, 7)
+    tg, hg = {}, {}
+    torc.grad_sync = lambda g: tg.setdefault(len(tg), g.detach().clone())
+    hipc.grad_sync = lambda g: hg.setdefault(len(hg), g.detach().clone())
+    p_t = torc.update(b)
+    p_h = hipc.update(b).clone()
+    torch.testing.assert_close(p_h, p_t, rtol=2e-4, atol=1e-6)
+    lay = hipc.layout
+    for net, k in ((lay.critic, 0), (lay.actor, 1)):
+        scale = tg[k].abs().max().item()
+        torch.testing.assert_close(hg[k], tg[k], rtol=0, atol=2e-4 * scale)
+        # per layer, so that a wrong small tensor cannot hide behind a large one
+        for s in net.layers:
+            for off, n in ((s.w_off, s.w_numel), (s.b_off, s.out_dim)):
+                a_, b_ = hg[k][off - net.base: off - net.base + n], tg[k][off - net.base: off - net.base + n]
+                if b_.norm() > 1e-10:
+                    rel = ((a_ - b_).norm() / b_.norm()).item()
+                    assert rel < 2e-4, (k, off, rel)
+
+
+@pytest.mark.parametrize("model,kw", CASES)
+@pytest.mark.parametrize("graph", [False, True])
+def test_f32_core_tracks_torch_core(model, kw, graph):
+    """Same bounds as the per-layer fp32 kernels (tests/test_hip_kernels.py), with the optimiser fused
+    into the weight-gradient kernel."""
+    from d4pg_pytorch_amd.models.core import TorchCore, build_core
+    from d4pg_pytorch_amd.models.nets import refresh_shadows32
+    cfg = _cfg(model, use_hip_graph=graph, **kw)
+    hipc, torc = build_core(cfg, "cuda"), TorchCore(cfg, "cuda")
+    torch.testing.assert_close(hipc.online.flat, torc.online.flat.detach())
+    for it in range(6):
+        b = _batch(cfg, 100 + it)
+        p1 = hipc.update(b).clone()
+        p2 = torc.update(b)
+        torch.testing.assert_close(p1, p2, rtol=2e-3, atol=1e-5)
+    # Adam normalises the step, so parameters agree to ~lr * (relative gradient error)
+    torch.testing.assert_close(hipc.online.flat, torc.online.flat.detach(), rtol=0, atol=2e-5)
+    torch.testing.assert_close(hipc.target.flat, torc.target.flat, rtol=0, atol=2e-6)
+    mh, mt = hipc.read_metrics(), torc.read_metrics()
+    assert mh["count"] == 6 and mt["count"] == 6
+    assert abs(mh["value_loss"] - mt["value_loss"]) < 1e-3 * max(1.0, abs(mt["value_loss"]))
+    assert abs(mh["policy_loss"] - mt["policy_loss"]) < 1e-3 * max(1.0, abs(mt["policy_loss"]))
+    assert hipc.read_dev_state().step_done == 6
+    # packed copies written by the optimiser inside the weight-gradient kernel == a rebuild from the masters
+    for flat, sh, target in ((hipc.online.flat, hipc.shadow_online, False), (hipc.target.flat, hipc.shadow_target, True)):
+        want = torch.zeros_like(sh)
+        refresh_shadows32(flat.detach(), want, hipc.layout, hipc.sl)
+        for slots in (hipc.sl.actor, hipc.sl.critic):
+            for s in slots:
+                assert torch.equal(sh[s.f.off: s.f.off + s.f.numel], want[s.f.off: s.f.off + s.f.numel])
+                if s.b is not None and not target:        # the targets keep forward copies only
+                    assert torch.equal(sh[s.b.off: s.b.off + s.b.numel], want[s.b.off: s.b.off + s.b.numel])
+
+
+@pytest.mark.parametrize("per", [False, True])
+def test_f32_update_from_replay_and_resume(per, tmp_path):
+    from d4pg_pytorch_amd.models.core import build_core
+    from d4pg_pytorch_amd.replay.hbm_replay import HbmReplay
+    cfg = _cfg("d4pg", env="BipedalWalker-v2", replay_mem_size=50_000, replay_memory_prioritized=int(per))
+    core = build_core(cfg, "cuda")
+    rp = HbmReplay(cfg, "cuda", core.dev_state)
+    core.attach_replay(rp)
+    g = torch.Generator().manual_seed(1)
+    rows = torch.randn(20_000, rp.row_ld, generator=g)
+    S, A = rp.S, rp.A
+    rows[:, S + A + 1] = (torch.rand(20_000, generator=g) < 0.05).float()
+    rows[:, S + A + 2] = 0.99 ** 5
+    rp.insert(rows.cuda())
+    for _ in range(70):          # more than two drawn-ahead chunks of 32
+        prio = core.update_from_replay()
+    torch.cuda.synchronize()
+    m = core.read_metrics()
+    assert m["count"] == 70 and np.isfinite(m["value_loss"]) and np.isfinite(m["policy_loss"])
+    assert torch.isfinite(core.online.flat).all() and torch.all(prio > 0)
+    bundle = core.state_bundle()
+    other = build_core(_cfg("d4pg", env="BipedalWalker-v2", random_seed=3), "cuda")
+    other.load_state_bundle(bundle)
+    assert torch.equal(other.shadow_online, core.shadow_online)
+    b = _batch(cfg, 5)
+    core.update(b)
+    other.update(b)
+    torch.testing.assert_close(other.online.flat, core.online.flat, rtol=0, atol=0)
+
+
+def test_f32_drawn_ahead_chunks_equal_one_update_at_a_time():
+    """The 32-updates-per-graph path (batches drawn ahead and read in place, the critic's forward pass made
+    one update ahead) makes bit for bit the updates that drawing a batch per update makes."""
+    from d4pg_pytorch_amd.models.core import build_core
+    from d4pg_pytorch_amd.replay.hbm_replay import HbmReplay
+
+    def run(sample_ahead):
+        cfg = _cfg("d4pg", replay_mem_size=20_000, sample_ahead=sample_ahead)
+        core = build_core(cfg, "cuda")
+        rp = HbmReplay(cfg, "cuda", core.dev_state)
+        core.attach_replay(rp)
+        g = torch.Generator().manual_seed(3)
+        rows = torch.randn(10_000, rp.row_ld, generator=g)
+        rows[:, rp.S + rp.A + 1] = (torch.rand(10_000, generator=g) < 0.05).float()
+        rows[:, rp.S + rp.A + 2] = 0.99 ** 5
+        rp.insert(rows.cuda())
+        done = 0
+        while done < 48:
+            done += core.update_from_replay_many(48 - done)
+        torch.cuda.synchronize()
+        return core.online.flat.clone(), core.target.flat.clone()
+
+    p1, t1 = run(1)
+    p8, t8 = run(16)
+    assert torch.equal(p1, p8) and torch.equal(t1, t8)
