@@ -17,6 +17,11 @@ Configurations:
            one synchronous update consumes the global batch of N x 256 rows)
 Other shapes: --env Ant-v2 --batch 4096 --model d3pg --per ...
 
+Precision: the headline (``value``, ``dtype: fp32``) is the reference's own precision — every product an exact
+f32 multiply-add on the matrix cores.  For N == 1 the same run also times the bf16-operand pipeline and
+reports it as ``bf16_value`` / ``bf16_ms_per_step``.  A request of fewer than 256 steps is timed as 15
+regions of exactly that many updates each (``repeats``), and the median region is reported.
+
 Data-parallel modes (``--dp-mode``, N > 1):
   replicated      the sampled rows are all-gathered (one ~20 KB/rank collective, one update
                   ahead on a side stream) and every rank runs the update on the global
@@ -71,12 +76,19 @@ def parse_args():
     ap.add_argument("--per", action="store_true", help="prioritised replay (HBM sum-tree) instead of uniform")
     ap.add_argument("--replay-size", type=int, default=1_000_000)
     ap.add_argument("--prefill", type=int, default=200_000)
-    ap.add_argument("--dtype", default="bf16", choices=["fp32", "bf16"],
-                    help="bf16: fused row-local pipeline (bf16 MFMA operands, fp32 masters/accumulate); fp32: exact f32 MFMA")
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="fp32 (the reference's precision, the headline): fused row-local pipeline on exact f32 MFMA; "
+                         "bf16: the same pipeline with bf16 MFMA operands (fp32 masters / accumulate)")
+    ap.add_argument("--no-bf16", action="store_true",
+                    help="N == 1: do not also time the bf16 pipeline (reported as bf16_value next to the fp32 headline)")
+    ap.add_argument("--repeats", type=int, default=0,
+                    help="timed regions of exactly --steps updates each; the median is reported "
+                         "(0: 15 when --steps < 256, so that a short request is not a 1 ms sample, else 1)")
+    ap.add_argument("--layers", action="store_true", help="fp32 with one launch per layer (the unfused HIP kernels)")
     ap.add_argument("--baseline", action="store_true",
                     help="time the unfused eager-PyTorch update (reference op sequence) instead")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--tile-rows", default="auto", choices=["auto", "16", "32"])
+    ap.add_argument("--tile-rows", default="auto", choices=["auto", "4", "8", "16", "32"])
     ap.add_argument("--dp-mode", default="both", choices=["both", "replicated", "grad_allreduce"],
                     help="data-parallel scheme for N > 1 (see the module docstring)")
     ap.add_argument("--chunk", type=int, default=0,
@@ -129,6 +141,7 @@ def main() -> None:
     else:
         comm = TorchDistComm(device=device) if world > 1 else LocalComm()
 
+    repeats = args.repeats if args.repeats > 0 else (15 if args.steps < 256 else 1)
     env = args.env
     if env == "auto":
         env = "LunarLanderContinuous-v2" if world == 1 else "Walker2d-v2"
@@ -139,8 +152,9 @@ def main() -> None:
                          dense_size=400, num_atoms=51, v_min=vrange[0], v_max=vrange[1],
                          device="cuda", replay_mem_size=args.replay_size,
                          replay_memory_prioritized=int(args.per), use_hip_graph=not args.no_graph,
-                         compute_dtype=args.dtype, phase_tile_rows=args.tile_rows, num_steps_train=max(1, args.steps + args.warmup),
-                         fused_learner="torch" if args.baseline else "auto", random_seed=2019)
+                         compute_dtype=args.dtype, phase_tile_rows=args.tile_rows,
+                         num_steps_train=max(1, args.steps * max(1, repeats) + args.warmup),
+                         fused_learner="torch" if args.baseline else ("layers" if args.layers else "auto"), random_seed=2019)
     if args.chunk > 0:
         cfg["sample_ahead"] = args.chunk
     S, A = cfg["state_dim"], cfg["action_dim"]
@@ -166,13 +180,17 @@ def main() -> None:
                     one_step()
                     done += 1
         run(args.warmup)
-        comm.barrier()
-        torch.cuda.synchronize(device)
-        t0 = time.perf_counter()
-        run(args.steps)
-        comm.barrier()
-        torch.cuda.synchronize(device)
-        return comm.all_reduce_max_scalar(time.perf_counter() - t0)
+        times = []
+        for _ in range(repeats):
+            comm.barrier()
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            run(args.steps)
+            comm.barrier()
+            torch.cuda.synchronize(device)
+            times.append(comm.all_reduce_max_scalar(time.perf_counter() - t0))
+        times.sort()
+        return times[len(times) // 2]
 
     extra = {}
     dp_mode = "none"
@@ -226,6 +244,17 @@ def main() -> None:
             torch.cuda.empty_cache()
         if world == 1 and not args.dp_selftest:
             core, dt = run_grad_allreduce()
+            if args.dtype == "fp32" and not args.no_bf16 and not args.layers:
+                # the same configuration on the bf16-operand pipeline, for reference next to the headline
+                metrics_primary = core.read_metrics()
+                cfg_main, cfg = cfg, dict(cfg, compute_dtype="bf16")
+                try:
+                    _, dt_b = run_grad_allreduce()
+                    extra["bf16_value"] = round(args.steps / dt_b, 2)
+                    extra["bf16_ms_per_step"] = round(1000.0 * dt_b / args.steps, 5)
+                except Exception as exc:
+                    extra["bf16_error"] = repr(exc)[:200]
+                cfg = cfg_main
         elif args.dp_mode != "both":
             dp_mode = args.dp_mode
             core, dt = run_replicated() if dp_mode == "replicated" else run_grad_allreduce()
@@ -257,6 +286,7 @@ def main() -> None:
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "repeats": repeats,
             "ms_per_step": round(1000.0 * dt / args.steps, 5),
             "higher_is_better": True,
             "scaling": "weak",
@@ -270,7 +300,9 @@ def main() -> None:
             "value_loss": metrics["value_loss"],
             "policy_loss": metrics["policy_loss"],
             "implementation": "eager-torch-unfused" if args.baseline else
-                              (("hip-fused-rowlocal-bf16" if args.dtype == "bf16" else "hip-kernels-fp32-mfma")
+                              (type(core).__name__ + ":" +
+                               {"HipCoreF32": "hip-fused-rowlocal-fp32-mfma", "HipCoreBf16": "hip-fused-rowlocal-bf16",
+                                "HipCore": "hip-per-layer-fp32-mfma"}.get(type(core).__name__, "?")
                                + ("" if args.no_graph else "+hipgraph")),
             "config": {"model": "%s %s (S=%d, A=%d, H=400%s)" % (
                            env, args.model.upper(), S, A, ", 51 atoms" if args.model == "d4pg" else ""),

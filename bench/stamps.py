@@ -2,7 +2,7 @@
 """Per-layer timing inside the fused phase kernels (diagnostic build only).
 
     D4PG_STAMPS=1 python -m d4pg_pytorch_amd.build --force
-    python bench/stamps.py
+    python bench/stamps.py [batch] [bf16|fp32]
 
 Workgroup 0 of ``critic_phase_kernel`` / ``actor_phase_kernel`` stamps the 100 MHz wall
 clock at every layer seam; this script runs a few updates and prints the deltas in µs.
@@ -28,13 +28,14 @@ ACTOR = ["prologue", "cf1", "cf2", "cf3", "loss", "cb3", "cb2", "cb1", "ab3", "a
 
 def main():
     batch = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    dtype = sys.argv[2] if len(sys.argv) > 2 else "bf16"
     cfg = default_config(env="LunarLanderContinuous-v2", model="d4pg", batch_size=batch, device="cuda",
-                         v_min=-200.0, v_max=200.0, compute_dtype="bf16", replay_mem_size=100_000)
+                         v_min=-200.0, v_max=200.0, compute_dtype=dtype, replay_mem_size=100_000)
     core = build_core(cfg, "cuda")
     rp = HbmReplay(cfg, "cuda", core.dev_state)
     core.attach_replay(rp)
     rp.insert(synthetic_rows(50_000, rp.S, rp.A, rp.row_ld, 0.95, "cuda", 1))
-    fn = H.lib().d4pg_read_stamps
+    fn = H.lib().d4pg_read_stamps if dtype == "bf16" else H.lib().d4pg_read_stamps32
     acc = None
     n = 0
     for it in range(60):
@@ -46,6 +47,9 @@ def main():
         torch.cuda.synchronize()
         buf = (C.c_ulonglong * 64)()
         assert fn(buf) == 0
+        if dtype != "bf16":
+            # the span stamps are running minima / maxima: re-arm them before the next burst
+            H.lib().d4pg_reset_stamps32()
         if it < 10:
             continue
         v = list(buf)
@@ -58,6 +62,8 @@ def main():
         acc = rows if acc is None else [[a + b for a, b in zip(ra, rb)] for ra, rb in zip(acc, rows)]
         n += 1
     out = {}
+    if dtype != "bf16":
+        v = v + [0] * 64
     out["loss_detail_last_iter"] = {"cf3_barrier_to_row0_start": (v[16] - v[9]) / 100.0, "row0_math": (v[17] - v[16]) / 100.0,
                                     "row0_stores": (v[18] - v[17]) / 100.0, "row1_total": (v[19] - v[18]) / 100.0,
                                     "row1_end_to_barrier": (v[10] - v[19]) / 100.0}
@@ -67,6 +73,12 @@ def main():
                               "lds_write_and_barrier": (v[32 + 23] - v[32 + 22]) / 100.0,
                               "reduce_adam_stores_issued": (v[32 + 24] - v[32 + 23]) / 100.0,
                               "actor_phase_end_to_wgrad_entry": (v[32 + 20] - v[32 + 9]) / 100.0}
+    if dtype != "bf16":
+        base = v[31]      # workgroup 0 entry
+        out["critic_launch_spans_last_iter_us_rel_wg0_entry"] = {
+            "critic_role_first_start": (v[20] - base) / 100.0, "critic_role_last_end": (v[21] - base) / 100.0,
+            "actor_fwd_role_first_start": (v[22] - base) / 100.0, "actor_fwd_role_last_end": (v[23] - base) / 100.0,
+            "warmers_last_end": (v[25] - base) / 100.0}
     for names, r, key in ((CRITIC, acc[0], "critic_phase"), (ACTOR, acc[1], "actor_phase")):
         out[key] = {nm: round(x / n, 2) for nm, x in zip(names, r)}
         out[key]["total_us"] = round(sum(r) / n, 2)

@@ -28,6 +28,39 @@
 #endif
 #define D4PG_MAIN_UNIT (D4PG_KSH_PART == 99 || D4PG_KSH_PART == -1)
 
+// Diagnostic build (-DD4PG_STAMPS, single translation unit): workgroup 0 records the 100 MHz wall clock at
+// every layer seam of the phase kernels; read back with d4pg_read_stamps32 (bench/stamps.py --dtype fp32).
+#ifdef D4PG_STAMPS
+__device__ unsigned long long g_stamps32[2][32];
+#define STAMP(k, i)                                                                    \
+    do {                                                                               \
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_stamps32[k][i] = wall_clock64();    \
+    } while (0)
+// earliest start / latest end over ALL workgroups of a role (slots 20.. of the kernel's row)
+#define STAMP_SPAN(k, i, is_end)                                                                       \
+    do {                                                                                               \
+        if (threadIdx.x == 0) {                                                                        \
+            if (is_end) atomicMax(&g_stamps32[k][i], wall_clock64());                                  \
+            else atomicMin(&g_stamps32[k][i], wall_clock64());                                         \
+        }                                                                                              \
+    } while (0)
+#if D4PG_KSH_PART != 99
+#error "the stamp build keeps everything in one translation unit (one g_stamps32 symbol)"
+#endif
+D4PG_API int d4pg_read_stamps32(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps32), sizeof(g_stamps32));
+}
+D4PG_API int d4pg_reset_stamps32() {      // re-arm the running minima (slots 20, 22) and maxima
+    unsigned long long h[2][32];
+    for (int k = 0; k < 2; ++k)
+        for (int i = 0; i < 32; ++i) h[k][i] = (i == 20 || i == 22) ? ~0ull : 0ull;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps32), h, sizeof(h));
+}
+#else
+#define STAMP(k, i)
+#define STAMP_SPAN(k, i, is_end)
+#endif
+
 constexpr int NW32 = 8;          // waves per phase workgroup: one unit (column tile or K-slice) each
 constexpr int LDS_PAD32 = 4;     // floats appended to every LDS row: the 4 rows of one wide read hit disjoint banks
 
@@ -316,8 +349,10 @@ __device__ __forceinline__ void critic_tail(const CriticPhaseArgs32& a, Chain32<
     constexpr int M = 4 * MT;
     const PhaseDims& d = a.d;
     __syncthreads();
+    STAMP(0, 9);
     critic_rows<1, M>(d, CriticRowsOut{a.dlT, a.per_loss, a.priority}, row0, lane, wave, lg_t, lg_o, dlg, sp, rs);
     __syncthreads();
+    STAMP(0, 10);
     const int ldh = d.ldh, Bp = d.Bp;
     float* const dh2T = a.dh2T;
     float* const dh1T = a.dh1T;
@@ -328,11 +363,16 @@ __device__ __forceinline__ void critic_tail(const CriticPhaseArgs32& a, Chain32<
         put_stash4(dh2T, Bp, col, row0 + r0, v);
     }, [&] { ch.template prefetch<0>(a.cb2); });
     __syncthreads();
+    STAMP(0, 11);
     ch.template hidden<0>(bufD, ldh, a.cb2, [=](int r0, int col, f32x4 v) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = bufC[(r0 + r) * ldh + col] > 0.f ? v[r] : 0.f;
         put_stash4(dh1T, Bp, col, row0 + r0, v);
     }, [] {});
+#ifdef D4PG_STAMPS
+    __syncthreads();
+#endif
+    STAMP(0, 12);
 }
 
 template <int MT, int KSH, int KSN>
@@ -355,20 +395,27 @@ __global__ __launch_bounds__(64 * NW32) void critic_phase32_kernel(const CriticP
         warm_layer(a.tc[0], sl, nsl, acc);
         warm_layer(a.tc[1], sl, nsl, acc);
         warm_layer(a.tc[2], sl, nsl, acc);
-        warm_layer(a.cf[0], sl, nsl, acc);
-        warm_layer(a.cf[1], sl, nsl, acc);
-        warm_layer(a.cf[2], sl, nsl, acc);
+        if (a.ahead.mode == 0) {      // (else the online critic's forward pass was most likely made ahead)
+            warm_layer(a.cf[0], sl, nsl, acc);
+            warm_layer(a.cf[1], sl, nsl, acc);
+            warm_layer(a.cf[2], sl, nsl, acc);
+        }
         warm_layer(a.cb3, sl, nsl, acc);
         warm_layer(a.cb2, sl, nsl, acc);
         asm volatile("" ::"v"(acc));
+        STAMP_SPAN(0, 25, true);
         return;
     }
     if (row0 >= d.B) {         // the second half of the grid: actor forward (+ the per-update tick)
+        STAMP_SPAN(0, 22, false);
         if (a.pk.do_tick && row0 == d.B && threadIdx.x == 0)
             devstate_tick(a.pk.st, a.pk.beta1, a.pk.beta2, a.pk.per_b0, a.pk.per_b1, a.pk.total_steps);
         actor_forward_role<MT, KSH, KSN>(a, row0 - d.B, smem);
+        STAMP_SPAN(0, 23, true);
         return;
     }
+    STAMP_SPAN(0, 20, false);
+    STAMP(0, 31);
     int off = 0;
     auto carve = [&](int bytes) { char* p = smem + off; off += (bytes + 15) & ~15; return p; };
     float* xin = (float*)carve(M * d.ldx * 4);     // [s | a]
@@ -416,6 +463,7 @@ __global__ __launch_bounds__(64 * NW32) void critic_phase32_kernel(const CriticP
     if (a.ahead.mode != 0 && a.pk.enabled)
         ahead_ok = a.pk.st->pad_[AHEAD_STEP] == a.pk.st->step_done + 1 &&
                    a.pk.st->pad_[AHEAD_ROWS] == (long long)(uintptr_t)src_sa.base;
+    STAMP(0, 0);
     if (ahead_ok) {
         copy16(bufC, a.ahead.h1 + (size_t)row0 * d.ldh, M * d.ldh * 4);
         copy16(bufD, a.ahead.h2 + (size_t)row0 * d.ldh, M * d.ldh * 4);
@@ -433,6 +481,7 @@ __global__ __launch_bounds__(64 * NW32) void critic_phase32_kernel(const CriticP
         rs[3 * M + threadIdx.x] = rs_w;
     }
     __syncthreads();
+    STAMP(0, 1);
 
     const int ldh = d.ldh, ldx = d.ldx, nop = d.nop, Bp = d.Bp, S = d.S;
     float* const h1T = a.h1T;
@@ -447,19 +496,24 @@ __global__ __launch_bounds__(64 * NW32) void critic_phase32_kernel(const CriticP
     // ---- target actor: s' -> a' (written into the action columns of xin2) ----
     ch.template narrow<0>(xin2, d.ldx, a.ta[0], relu_to(bufA), [&] { ch.template prefetch<1>(a.ta[1]); });
     __syncthreads();
+    STAMP(0, 2);
     ch.template hidden<1>(bufA, d.ldh, a.ta[1], relu_to(bufB), [&] { ch.template prefetch<0>(a.ta[2]); });
     __syncthreads();
+    STAMP(0, 3);
     ch.template split<0>(bufB, d.ldh, a.ta[2], [=](int r0, int col, f32x4 v) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fast_tanh(v[r]);
         put_lds4(xin2, ldx, r0, S + col, v);
     }, [&] { ch.template prefetch<1>(a.tc[0]); });
     __syncthreads();
+    STAMP(0, 4);
     // ---- target critic: (s', a') -> logits_t ----
     ch.template narrow<1>(xin2, d.ldx, a.tc[0], relu_to(bufA), [&] { ch.template prefetch<0>(a.tc[1]); });
     __syncthreads();
+    STAMP(0, 5);
     ch.template hidden<0>(bufA, d.ldh, a.tc[1], relu_to(bufB), [&] { ch.template prefetch<1>(a.tc[2]); });
     __syncthreads();
+    STAMP(0, 6);
     // With the online critic's tiles made ahead its three layers are skipped; the first of them is
     // prefetched by the layer before, so skipping is expressed as a layer without tiles (every load of it
     // out of range), with the fields selected one by one (see csrc/fused.hip).
@@ -494,6 +548,7 @@ __global__ __launch_bounds__(64 * NW32) void critic_phase32_kernel(const CriticP
     // here and lands while the loss rows are computed.
     ch.template prefetch<1>(a.cb3);
     critic_tail<MT, KSH, KSN>(a, ch, row0, lane, wave, lg_t, lg_o, dlg, sp, rs, bufC, bufD);
+    STAMP_SPAN(0, 21, true);
 }
 
 // ---- the online critic's forward pass for the NEXT update, in extra workgroups of the actor phase ----
@@ -581,6 +636,7 @@ __global__ __launch_bounds__(64 * NW32) void actor_phase32_kernel(const ActorPha
         tree_update_body<NW32>(a.tree);
         return;
     }
+    STAMP(1, 31);
     int off = 0;
     auto carve = [&](int bytes) { char* p = smem + off; off += (bytes + 15) & ~15; return p; };
     float* xin = (float*)carve(M * d.ldx * 4);     // [s | pi(s)]
@@ -602,6 +658,7 @@ __global__ __launch_bounds__(64 * NW32) void actor_phase32_kernel(const ActorPha
     zero_tail(bufC, d.ldh, M, d.H);
     zero_tail(bufD, d.ldh, M, d.H);
     __syncthreads();
+    STAMP(1, 0);
     const int ldh = d.ldh, ldx = d.ldx, nop = d.nop, Bp = d.Bp, S = d.S, lda_ = d.lda_;
     float* const daT = a.daT;
     float* const dh2T = a.dh2T;
@@ -616,16 +673,20 @@ __global__ __launch_bounds__(64 * NW32) void actor_phase32_kernel(const ActorPha
     // ---- critic forward at (s, pi(s)) ----
     ch.template narrow<0>(xin, d.ldx, a.cf[0], relu_to(bufC), [&] { ch.template prefetch<1>(a.cf[1]); });
     __syncthreads();
+    STAMP(1, 1);
     ch.template hidden<1>(bufC, ldh, a.cf[1], relu_to(bufD), [&] { ch.template prefetch<0>(a.cf[2]); });
     __syncthreads();
+    STAMP(1, 2);
     ch.template split<0>(bufD, ldh, a.cf[2], [=](int r0, int col, f32x4 v) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) lg_o[(r0 + r) * nop + col] = v[r];
     }, [&] { ch.template prefetch<1>(a.cb3); });
     __syncthreads();
+    STAMP(1, 3);
     // ---- actor loss: -mean Q ----
     actor_rows<1, M>(d, a.q_val, row0, lane, wave, lg_o, dlg);
     __syncthreads();
+    STAMP(1, 4);
     // ---- critic backward (dX only) down to the action ----
     ch.template narrow<1>(dlg, d.ldd, a.cb3, [=](int r0, int col, f32x4 v) {
 #pragma unroll
@@ -633,12 +694,14 @@ __global__ __launch_bounds__(64 * NW32) void actor_phase32_kernel(const ActorPha
         put_lds4(bufD, ldh, r0, col, v);
     }, [&] { ch.template prefetch<0>(a.cb2); });
     __syncthreads();
+    STAMP(1, 5);
     ch.template hidden<0>(bufD, ldh, a.cb2, [=](int r0, int col, f32x4 v) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = bufC[(r0 + r) * ldh + col] > 0.f ? v[r] : 0.f;
         put_lds4(bufC, ldh, r0, col, v);
     }, [&] { ch.template prefetch<1>(a.cb1); });
     __syncthreads();
+    STAMP(1, 6);
     ch.template split<1>(bufC, ldh, a.cb1, [=](int r0, int col, f32x4 v) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -649,6 +712,7 @@ __global__ __launch_bounds__(64 * NW32) void actor_phase32_kernel(const ActorPha
         put_stash4(daT, Bp, col, row0 + r0, v);
     }, [&] { ch.template prefetch<0>(a.ab3); });
     __syncthreads();
+    STAMP(1, 7);
     // ---- actor backward ----
     ch.template narrow<0>(dab, lda_, a.ab3, [=](int r0, int col, f32x4 v) {
 #pragma unroll
@@ -657,11 +721,16 @@ __global__ __launch_bounds__(64 * NW32) void actor_phase32_kernel(const ActorPha
         put_stash4(dh2T, Bp, col, row0 + r0, v);
     }, [&] { ch.template prefetch<1>(a.ab2); });
     __syncthreads();
+    STAMP(1, 8);
     ch.template hidden<1>(bufB, ldh, a.ab2, [=](int r0, int col, f32x4 v) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = bufA[(r0 + r) * ldh + col] > 0.f ? v[r] : 0.f;
         put_stash4(dh1T, Bp, col, row0 + r0, v);
     }, [] {});
+#ifdef D4PG_STAMPS
+    __syncthreads();
+#endif
+    STAMP(1, 9);
 }
 
 // ---- host launchers -----------------------------------------------------------------------------
@@ -732,12 +801,21 @@ static int n_warmers32(const PhaseDims& d, int M) {
     if (d.B / M > 64) return 0;
     static const int n = [] {
         const char* e = getenv("D4PG_L2_WARMERS");
-        const int v = e ? atoi(e) : 32;
+        // measured per update at batch 256: 0: 84.8 us, 32: 89.5 (the warmers themselves, which miss in L2 by
+        // design, then end the launch 6 us after the last row tile), 64: 80.9, 128: 81.3
+        const int v = e ? atoi(e) : 64;
         return v < 0 ? 0 : (v > 256 ? 256 : (v + 7) & ~7);
     }();
     return n;
 }
 
+#ifdef D4PG_STAMPS       // one translation unit: only the 400-wide kernels are instantiated
+#define DISPATCH_PHASE32(LAUNCHER, LDSFN)                                                   \
+    const int lds = LDSFN(d, M, mt);                                                        \
+    const int grid = d.B / M + extra_blocks;                                                \
+    if (ksh == 13) return LAUNCHER<13>(a, mt, ksn, grid, lds, stream);                      \
+    return -10;
+#else
 #define DISPATCH_PHASE32(LAUNCHER, LDSFN)                                                   \
     const int lds = LDSFN(d, M, mt);                                                        \
     const int grid = d.B / M + extra_blocks;                                                \
@@ -745,6 +823,7 @@ static int n_warmers32(const PhaseDims& d, int M) {
     if (ksh == 4) return LAUNCHER<4>(a, mt, ksn, grid, lds, stream);                        \
     if (ksh == 8) return LAUNCHER<8>(a, mt, ksn, grid, lds, stream);                        \
     return -10;
+#endif
 
 D4PG_API int d4pg_critic_phase32(const CriticPhaseArgs32* a, int mt, hipStream_t stream) {
     const PhaseDims& d = a->d;

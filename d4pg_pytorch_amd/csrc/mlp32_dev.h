@@ -54,9 +54,12 @@ struct LayerW32 {
 struct Chunk32 {
     f32x4 b[KCH];
 };
-// the first chunk of a wave's unit of some layer, fetched while the layer before it still runs
+// The first PF chunks of a wave's unit of some layer, fetched while the layer before it still runs: the
+// stream of weight loads of a workgroup must not stop at a layer boundary (a layer is as fast as the
+// loads it keeps in flight; with one chunk fetched ahead a boundary cost ~0.6 us of idle load pipe).
+constexpr int PF32 = 2;
 struct Pre32 {
-    Chunk32 c;
+    Chunk32 c[PF32];
     float bias;
 };
 
@@ -66,6 +69,7 @@ struct WSrc32 {
     __amdgpu_buffer_rsrc_t rsrc;
     int voff;
     int soff;
+    int oob;       // an offset beyond the descriptor: loads from it return zeros without touching memory
 };
 __device__ __forceinline__ WSrc32 wsrc_of(const LayerW32& L, int wave, int lane) {
     const int bytes = L.ntiles * L.ks * CHUNK_BYTES;
@@ -77,13 +81,16 @@ __device__ __forceinline__ WSrc32 wsrc_of(const LayerW32& L, int wave, int lane)
     s.voff = (has && tile * 64 + lane < L.N) ? lane * 16 : bytes;
     // unit of wave w: chunks [w * nch, (w + 1) * nch) of the packed copy (nch = ks when the tiles are dealt out)
     s.soff = has ? wave * L.nch * CHUNK_BYTES : 0;
+    s.oob = bytes;
     return s;
 }
-__device__ __forceinline__ Chunk32 load_chunk(const WSrc32& s, int chunk) {
+// chunk `chunk` of the unit; `exists` false: a chunk beyond the unit (all lanes out of range)
+__device__ __forceinline__ Chunk32 load_chunk(const WSrc32& s, int chunk, bool exists = true) {
     Chunk32 c;
+    const int voff = exists ? s.voff : s.oob;
 #pragma unroll
     for (int g = 0; g < KCH; ++g)
-        c.b[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(s.rsrc, s.voff,
+        c.b[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(s.rsrc, voff,
                                                                                 s.soff + chunk * CHUNK_BYTES + g * 1024, 0));
     // The loads stay HERE in the instruction stream: left alone, the scheduler sinks every load to
     // just ahead of its first use (fewer live registers), which leaves one load in flight per wave.
@@ -96,7 +103,9 @@ __device__ __forceinline__ Pre32 fetch_first(const LayerW32& L, int wave, int la
     Pre32 t;
     const int col = (L.ksplit > 1 ? 0 : wave * 64) + lane;
     t.bias = L.bias[col < L.N ? col : 0];
-    t.c = load_chunk(wsrc_of(L, wave, lane), 0);
+    const WSrc32 src = wsrc_of(L, wave, lane);
+#pragma unroll
+    for (int j = 0; j < PF32; ++j) t.c[j] = load_chunk(src, j, j < L.nch);
     return t;
 }
 
@@ -121,18 +130,21 @@ __device__ __forceinline__ void mma_chunk(const Chunk32& c, const float* Arow, i
 // the streaming loop is straight-line code with three chunk buffers in rotation (the chunk being
 // multiplied + two in flight; measured on one CU, a 400 x 400 layer on a 4-row tile: 6.1 us with
 // three, 6.5 with four, 6.9 with five buffers, 5.3 us for the loads alone, which is the rate at which
-// one CU's vector cache delivers 16-byte loads).
+// one CU is served by its L2).
 // RT = true: the unit has L.nch <= NCH chunks, known at run time (layers whose K is an input,
 // action or atom count).  All NCH chunks are loaded up front; the ones beyond L.nch use an
 // out-of-range offset (zeros, no memory traffic) and are not multiplied.
 //
 // epi(row0, col, v): v = rows row0 .. row0 + 3 of output column col (bias added), col < L.N.
 // A   : LDS fp32 [4 * MT][lda], columns up to 32 * L.ks readable (zero beyond the true K)
-// t   : the first chunk of this wave's unit (fetch_first, issued by the layer before)
+// t   : the first PF32 chunks of this wave's unit (fetch_first, issued by the layer before)
 // red : LDS scratch for the K-slice partial sums, (NW - 1) * MT * 256 floats
 // One unit per wave, so max(ntiles, ksplit) <= NW.  With ksplit > 1 the slices of the tile meet
 // through `red` behind one workgroup barrier, and wave 0 finishes the tile (fixed summation order).
-// `pre` issues the loads of the NEXT layer's first chunk; it is called at one place.
+// `pre` issues the loads of the NEXT layer's first chunks.  It is called at ONE place, right behind
+// this layer's own last load, so that the two streams join without a gap.  There is no branch around
+// the streaming code: every load is unconditional (so the compiler's count of the loads in flight is
+// exact) and a wave without a unit multiplies the zeros it loaded, on a SIMD that would otherwise idle.
 template <int NW, int MT, int NCH, bool RT, typename F, typename P>
 __device__ __forceinline__ void layer32(Pre32& t, const float* A, int lda, const LayerW32& L, float* red, F&& epi,
                                         P&& pre) {
@@ -141,40 +153,35 @@ __device__ __forceinline__ void layer32(Pre32& t, const float* A, int lda, const
     const bool split = L.ksplit > 1;
     const bool has = wave < (split ? L.ksplit : L.ntiles);
     const int col = (split ? 0 : wave * 64) + lane;
-    const int slice = split ? wave : 0;
+    const int slice = (split && has) ? wave : 0;
     f32x4 acc[MT][2];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt][0] = acc[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     const WSrc32 src = wsrc_of(L, wave, lane);
     const float* Al = A + (lane & 3) * lda + slice * L.nch * 32;
     constexpr int RING = RT ? NCH : (NCH < 3 ? NCH : 3);
+    constexpr int HAVE = PF32 < RING ? PF32 : RING;         // chunks that arrive in `t`
     Chunk32 ring[RING];
-    ring[0] = t.c;
-    // every load is unconditional (waves without a unit read zeros): the waits below are exact
-    auto fetch = [&](int c) {
-        if constexpr (RT) {
-            WSrc32 s2 = src;
-            s2.voff = c < L.nch ? src.voff : L.ntiles * L.ks * CHUNK_BYTES;
-            return load_chunk(s2, c);
-        } else {
-            return load_chunk(src, c);
+#pragma unroll
+    for (int c = 0; c < HAVE; ++c) ring[c] = t.c[c];
+#pragma unroll
+    for (int c = HAVE; c < RING; ++c) ring[c] = load_chunk(src, c, !RT || c < L.nch);
+    constexpr int PRE_AT = (RT || NCH <= RING) ? 0 : NCH - RING;      // behind the refill that is this layer's last load
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if constexpr (PRE_AT == 0) {
+            if (c == 0) pre();
         }
-    };
-    if constexpr (RING > 1) ring[1] = fetch(1);
-    pre();
-#pragma unroll
-    for (int c = 2; c < RING; ++c) ring[c] = fetch(c);
-    if (has) {
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            if (!RT || c < L.nch) mma_chunk<MT>(ring[c % RING], Al + c * 32, lda, acc);
-            if constexpr (!RT) {
-                if (c + RING < NCH) ring[c % RING] = fetch(c + RING);
-            }
+        if (!RT || c < L.nch) mma_chunk<MT>(ring[c % RING], Al + c * 32, lda, acc);
+        if constexpr (!RT) {
+            if (c + RING < NCH) ring[c % RING] = load_chunk(src, c + RING);
         }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt][0] += acc[mt][1];
+        if constexpr (PRE_AT > 0) {
+            if (c + 1 == PRE_AT) pre();
+        }
     }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt][0] += acc[mt][1];
     if (split) {       // workgroup-uniform
         if (has && slice != 0) {
 #pragma unroll
@@ -182,7 +189,7 @@ __device__ __forceinline__ void layer32(Pre32& t, const float* A, int lda, const
                 *reinterpret_cast<f32x4*>(red + ((size_t)((slice - 1) * MT + mt) * 64 + lane) * 4) = acc[mt][0];
         }
         __syncthreads();
-        if (slice != 0) return;
+        if (wave != 0) return;
         for (int s = 1; s < L.ksplit; ++s) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)

@@ -16,11 +16,11 @@ Here:
   targets, both Adam states, the update step and the config: real resume;
 * :func:`import_legacy_actor` reads a whole-module pickle written by the
   reference and returns its ``state_dict`` without importing the reference's
-  modules (a restricted unpickler maps its classes onto stubs).
+  modules and without executing anything from the file (``weights_only=True``
+  plus an exact allowlist of four stand-in classes and two torch layers).
 """
 from __future__ import annotations
 
-import io
 import os
 import pickle
 from collections import OrderedDict
@@ -47,11 +47,14 @@ def save_actor(path: str, state_dict: Dict[str, torch.Tensor], meta: Optional[Di
     return path
 
 
-def load_actor(path: str) -> Dict[str, torch.Tensor]:
-    """Returns a reference-layout ``state_dict`` from any supported actor file."""
+def load_actor(path: str, allow_legacy: bool = False) -> Dict[str, torch.Tensor]:
+    """Returns a reference-layout ``state_dict`` from any supported actor file.  A whole-module pickle
+    written by the reference is only accepted with ``allow_legacy=True`` (:func:`import_legacy_actor`)."""
     try:
         obj = torch.load(path, map_location="cpu", weights_only=True)
-    except Exception:
+    except pickle.UnpicklingError:
+        if not allow_legacy:
+            raise
         return import_legacy_actor(path)
     if isinstance(obj, dict) and obj.get("format") == ACTOR_FORMAT:
         return obj["state_dict"]
@@ -84,48 +87,39 @@ def load_learner_bundle(path: str) -> Dict[str, Any]:
 # ---------------------------------------------------------------------------
 # legacy whole-module pickles
 # ---------------------------------------------------------------------------
+# The reference writes ``torch.save(self.actor, path)`` (models/agent.py:161): a pickle of the whole
+# ``models.d{3,4}pg.networks.PolicyNetwork`` object.  It is read with ``torch.load(weights_only=True)``
+# — torch's own no-code unpickler, which builds tensors and containers and refuses every global that is
+# not on its allowlist — with exactly these additions to that allowlist, by exact (module, name):
+#
+# * stand-ins for the reference's two network classes (plain ``nn.Module`` subclasses with no code of
+#   their own, registered under the reference's module paths so that nothing of the reference is imported);
+# * ``torch.nn.Linear`` and ``torch.nn.BatchNorm1d``, the only submodules those networks hold
+#   (models/d4pg/networks.py:23-25,59-61; models/d3pg/networks.py:19).
+#
+# Nothing is matched by prefix, no ``getattr``, no numpy / copyreg / builtins callables: a file that names
+# ``os.system``, ``torch.hub.load`` or anything else is refused by the unpickler before anything runs.
 
-class _LegacyModule(torch.nn.Module):
-    """Stand-in for ``models.d{3,4}pg.networks.{PolicyNetwork,ValueNetwork}``."""
-
-    def __init__(self, *a, **k):   # never called by unpickling (copyreg.__newobj__ bypasses it)
-        super().__init__()
-
-
-_SAFE_PREFIXES = ("torch.", "collections", "numpy", "_codecs", "copyreg", "builtins")
-_SAFE_BUILTINS = {"set", "frozenset", "dict", "list", "tuple", "int", "float", "bool", "str", "bytes",
-                  "complex", "slice", "range", "object", "getattr"}
-
-
-class _LegacyUnpickler(pickle.Unpickler):
-    def find_class(self, module: str, name: str):
-        if module.startswith("models.") and name in ("PolicyNetwork", "ValueNetwork"):
-            return _LegacyModule
-        if module in ("builtins", "__builtin__"):      # protocol-2 pickles spell it the python-2 way
-            if name not in _SAFE_BUILTINS:
-                raise pickle.UnpicklingError(f"refusing builtins.{name}")
-            return super().find_class("builtins", name)
-        if module == "torch" or module.startswith(_SAFE_PREFIXES):
-            return super().find_class(module, name)
-        raise pickle.UnpicklingError(f"refusing to import {module}.{name} from a legacy checkpoint")
+_LEGACY_CLASSES = tuple((f"models.{algo}.networks", name)
+                        for algo in ("d4pg", "d3pg") for name in ("PolicyNetwork", "ValueNetwork"))
 
 
-class _LegacyPickleModule:
-    """``pickle_module`` shim for ``torch.load``."""
-    __name__ = "legacy_pickle"
-    Unpickler = _LegacyUnpickler
-    load = staticmethod(lambda f, **kw: _LegacyUnpickler(f, **kw).load())
-    loads = staticmethod(lambda b, **kw: _LegacyUnpickler(io.BytesIO(b), **kw).load())
-    dump = staticmethod(pickle.dump)
-    dumps = staticmethod(pickle.dumps)
-    PicklingError = pickle.PicklingError
-    UnpicklingError = pickle.UnpicklingError
-    HIGHEST_PROTOCOL = pickle.HIGHEST_PROTOCOL
+def _legacy_stub(module: str, name: str) -> type:
+    cls = type(name, (torch.nn.Module,), {"__module__": module, "__qualname__": name,
+                                           "__doc__": f"stand-in for the reference's {module}.{name}"})
+    return cls
+
+
+def _legacy_allowlist():
+    stubs = [_legacy_stub(m, n) for m, n in _LEGACY_CLASSES]
+    return stubs + [torch.nn.modules.linear.Linear, torch.nn.modules.batchnorm.BatchNorm1d]
 
 
 def import_legacy_actor(path: str) -> Dict[str, torch.Tensor]:
-    """Extract ``state_dict`` from a reference-style ``torch.save(module)`` file."""
-    obj = torch.load(path, map_location="cpu", pickle_module=_LegacyPickleModule, weights_only=False)
+    """Extract the ``state_dict`` from a reference-style ``torch.save(module)`` file without executing
+    anything the file names (see the allowlist above)."""
+    with torch.serialization.safe_globals(_legacy_allowlist()):
+        obj = torch.load(path, map_location="cpu", weights_only=True)
     if isinstance(obj, torch.nn.Module):
         sd = obj.state_dict()
     elif isinstance(obj, dict):

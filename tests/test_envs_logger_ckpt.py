@@ -159,17 +159,40 @@ def test_legacy_whole_module_pickle_import(tmp_path):
     sd = ck.import_legacy_actor(str(path))
     assert set(sd) == {"linear1.weight", "linear1.bias", "linear2.weight", "linear2.bias", "linear3.weight", "linear3.bias"}
     torch.testing.assert_close(sd["linear2.weight"], net.linear2.weight.detach())
-    assert "linear1.weight" in ck.load_actor(str(path))        # load_actor falls back to the importer
+    with pytest.raises(Exception):                              # the legacy reader is opt-in
+        ck.load_actor(str(path))
+    assert "linear1.weight" in ck.load_actor(str(path), allow_legacy=True)
 
 
 def test_legacy_importer_refuses_arbitrary_classes(tmp_path):
+    """Pickles that name a callable — directly, through a dotted name under an innocent module, or under the
+    torch namespace — are refused before anything runs."""
     import pickle
+    marker = tmp_path / "ran"
 
     class Evil:
         def __reduce__(self):
-            return (os.system, ("true",))
-    p = tmp_path / "evil.pt"
-    with open(p, "wb") as fh:
-        pickle.dump(Evil(), fh)
-    with pytest.raises(Exception):
-        ck.import_legacy_actor(str(p))
+            return (os.system, (f"touch {marker}",))
+
+    class EvilHub:
+        def __reduce__(self):
+            return (torch.hub.load, ("nowhere/nothing", "model"))
+
+    cases = {"os_system.pt": pickle.dumps(Evil()), "torch_hub.pt": pickle.dumps(EvilHub()),
+             # protocol 4 resolves dotted names: ('torch.serialization', 'os.system') is os.system
+             "dotted.pt": b"\x80\x04\x8c\x13torch.serialization\x8c\tos.system\x93\x8c\x04true\x85R.",
+             "getattr.pt": b"\x80\x04\x8c\x08builtins\x8c\x07getattr\x93."}
+    for name, blob in cases.items():
+        p = tmp_path / name
+        p.write_bytes(blob)
+        with pytest.raises(Exception):
+            ck.import_legacy_actor(str(p))
+        with pytest.raises(Exception):
+            ck.load_actor(str(p), allow_legacy=True)
+    # the same payloads inside a torch zip archive
+    for name, obj in (("zip_os.pt", Evil()), ("zip_hub.pt", EvilHub())):
+        p = tmp_path / name
+        torch.save(obj, p)
+        with pytest.raises(Exception):
+            ck.import_legacy_actor(str(p))
+    assert not marker.exists()
