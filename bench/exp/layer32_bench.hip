@@ -27,7 +27,7 @@ __global__ __launch_bounds__(64 * NW) void chain_kernel(LayerW32 L0, LayerW32 L1
     float* red = bufB + M * lda;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    Pre32 t0 = fetch_first(L0, wave, lane), t1;
+    Pre32 t0 = fetch_first<NCH0>(L0, wave, lane), t1;
     for (int i = threadIdx.x; i < M * lda; i += blockDim.x) {
         bufA[i] = x0[(size_t)blockIdx.x * M * lda + i];
         bufB[i] = 0.f;
@@ -37,12 +37,12 @@ __global__ __launch_bounds__(64 * NW) void chain_kernel(LayerW32 L0, LayerW32 L1
         layer32<NW, MT, NCH0, false>(t0, bufA, lda, L0, red, [=](int r0, int col, f32x4 v) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) bufB[(r0 + r) * lda + col] = fmaxf(v[r], 0.f);
-        }, [&] { t1 = fetch_first(L1, wave, lane); });
+        }, [&] { t1 = fetch_first<NCH1>(L1, wave, lane); });
         __syncthreads();
         layer32<NW, MT, NCH1, false>(t1, bufB, lda, L1, red, [=](int r0, int col, f32x4 v) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) bufA[(r0 + r) * lda + col] = fmaxf(v[r], 0.f);
-        }, [&] { t0 = fetch_first(L0, wave, lane); });
+        }, [&] { t0 = fetch_first<NCH0>(L0, wave, lane); });
         __syncthreads();
     }
     for (int i = threadIdx.x; i < M * lda; i += blockDim.x) out[(size_t)blockIdx.x * M * lda + i] = bufA[i];
@@ -72,7 +72,7 @@ static LayerW32 upload(const HostLayer& h, int ksplit) {
     CK(hipMalloc(&b, h.b.size() * 4));
     CK(hipMemcpy(w, h.packed.data(), h.packed.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(b, h.b.data(), h.b.size() * 4, hipMemcpyHostToDevice));
-    L.W = w, L.bias = b, L.ks = h.ks, L.ntiles = h.ntiles, L.N = h.N, L.ksplit = ksplit, L.nch = h.ks / ksplit, L.pad_ = 0;
+    L.W = w, L.bias = b, L.ks = h.ks, L.ntiles = h.ntiles, L.N = h.N, L.ksplit = ksplit, L.nch = h.ks / ksplit, L.kg = 8 * L.nch;
     return L;
 }
 

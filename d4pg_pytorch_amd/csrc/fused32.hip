@@ -78,12 +78,19 @@ struct Chain32 {
         lane = threadIdx.x & 63;
         wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     }
+    // prefetch of a layer by kind (h: hidden x hidden, s: K-sliced output layer, n: narrow K): the first
+    // chunks of the wave's unit into slot SLOT
     template <int SLOT>
-    __device__ __forceinline__ void prefetch(const LayerW32& L) {
-        if constexpr (SLOT == 0)
-            t0 = fetch_first(L, wave, lane);
-        else
-            t1 = fetch_first(L, wave, lane);
+    __device__ __forceinline__ void prefetch_h(const LayerW32& L) {
+        (SLOT == 0 ? t0 : t1) = fetch_first<KSH>(L, wave, lane);
+    }
+    template <int SLOT>
+    __device__ __forceinline__ void prefetch_s(const LayerW32& L) {
+        (SLOT == 0 ? t0 : t1) = fetch_first<split_nch(KSH)>(L, wave, lane);
+    }
+    template <int SLOT>
+    __device__ __forceinline__ void prefetch_n(const LayerW32& L) {
+        (SLOT == 0 ? t0 : t1) = fetch_first_rt(L, wave, lane);
     }
     // K = hidden width, N = hidden width: KSH chunks per column tile
     template <int SLOT, typename F, typename P>
@@ -306,7 +313,7 @@ __device__ __forceinline__ void actor_forward_role(const CriticPhaseArgs32& a, i
     float* bufB = (float*)carve(M * d.ldh * 4);    // h2
     float* red = (float*)carve((NW32 - 1) * MT * 256 * 4);
     Chain32<MT, KSH, KSN> ch(red);
-    ch.template prefetch<0>(f.af[0]);
+    ch.template prefetch_n<0>(f.af[0]);
     // (the epilogue lambdas capture scalars only: a closure that holds a copy of the kernel arguments
     // sends all of them through scratch memory, which also makes every buffer descriptor look divergent)
     const int ldh = d.ldh, ldx = d.ldx, Bp = d.Bp, S = d.S;
@@ -321,7 +328,7 @@ __device__ __forceinline__ void actor_forward_role(const CriticPhaseArgs32& a, i
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
         put_lds4(bufA, ldh, r0, col, v);
         put_stash4(h1T, Bp, col, row0 + r0, v);
-    }, [&] { ch.template prefetch<1>(f.af[1]); });
+    }, [&] { ch.template prefetch_h<1>(f.af[1]); });
     __syncthreads();
     copy16(f.g_h1 + (size_t)row0 * ldh, bufA, M * ldh * 4);
     ch.template hidden<1>(bufA, ldh, f.af[1], [=](int r0, int col, f32x4 v) {
@@ -329,7 +336,7 @@ __device__ __forceinline__ void actor_forward_role(const CriticPhaseArgs32& a, i
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
         put_lds4(bufB, ldh, r0, col, v);
         put_stash4(h2T, Bp, col, row0 + r0, v);
-    }, [&] { ch.template prefetch<0>(f.af[2]); });
+    }, [&] { ch.template prefetch_s<0>(f.af[2]); });
     __syncthreads();
     copy16(f.g_h2 + (size_t)row0 * ldh, bufB, M * ldh * 4);
     ch.template split<0>(bufB, ldh, f.af[2], [=](int r0, int col, f32x4 v) {
@@ -361,7 +368,7 @@ __device__ __forceinline__ void critic_tail(const CriticPhaseArgs32& a, Chain32<
         for (int r = 0; r < 4; ++r) v[r] = bufD[(r0 + r) * ldh + col] > 0.f ? v[r] : 0.f;
         put_lds4(bufD, ldh, r0, col, v);       // in place: each element is read and written by one lane
         put_stash4(dh2T, Bp, col, row0 + r0, v);
-    }, [&] { ch.template prefetch<0>(a.cb2); });
+    }, [&] { ch.template prefetch_h<0>(a.cb2); });
     __syncthreads();
     STAMP(0, 11);
     ch.template hidden<0>(bufD, ldh, a.cb2, [=](int r0, int col, f32x4 v) {
@@ -434,7 +441,7 @@ __global__ __launch_bounds__(64 * NW32) void critic_phase32_kernel(const CriticP
     // fit; a 16-row tile of a 400-wide network needs every byte of the LDS.
     float* red = critic_red_aliased(d) ? bufA : (float*)carve((NW32 - 1) * MT * 256 * 4);
     Chain32<MT, KSH, KSN> ch(red);
-    ch.template prefetch<0>(a.ta[0]);
+    ch.template prefetch_n<0>(a.ta[0]);
     const int SA = d.S + d.A;
     const RowSrc src_sa = a.pk.enabled ? packed_src(a.pk, 0) : plain_src(a.sa, d.ldx_in, d.B);
     const RowSrc src_s2 = a.pk.enabled ? packed_src(a.pk, SA + 3) : plain_src(a.s2, d.ldx_in, d.B);
@@ -494,35 +501,35 @@ __global__ __launch_bounds__(64 * NW32) void critic_phase32_kernel(const CriticP
         };
     };
     // ---- target actor: s' -> a' (written into the action columns of xin2) ----
-    ch.template narrow<0>(xin2, d.ldx, a.ta[0], relu_to(bufA), [&] { ch.template prefetch<1>(a.ta[1]); });
+    ch.template narrow<0>(xin2, d.ldx, a.ta[0], relu_to(bufA), [&] { ch.template prefetch_h<1>(a.ta[1]); });
     __syncthreads();
     STAMP(0, 2);
-    ch.template hidden<1>(bufA, d.ldh, a.ta[1], relu_to(bufB), [&] { ch.template prefetch<0>(a.ta[2]); });
+    ch.template hidden<1>(bufA, d.ldh, a.ta[1], relu_to(bufB), [&] { ch.template prefetch_s<0>(a.ta[2]); });
     __syncthreads();
     STAMP(0, 3);
     ch.template split<0>(bufB, d.ldh, a.ta[2], [=](int r0, int col, f32x4 v) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fast_tanh(v[r]);
         put_lds4(xin2, ldx, r0, S + col, v);
-    }, [&] { ch.template prefetch<1>(a.tc[0]); });
+    }, [&] { ch.template prefetch_n<1>(a.tc[0]); });
     __syncthreads();
     STAMP(0, 4);
     // ---- target critic: (s', a') -> logits_t ----
-    ch.template narrow<1>(xin2, d.ldx, a.tc[0], relu_to(bufA), [&] { ch.template prefetch<0>(a.tc[1]); });
+    ch.template narrow<1>(xin2, d.ldx, a.tc[0], relu_to(bufA), [&] { ch.template prefetch_h<0>(a.tc[1]); });
     __syncthreads();
     STAMP(0, 5);
-    ch.template hidden<0>(bufA, d.ldh, a.tc[1], relu_to(bufB), [&] { ch.template prefetch<1>(a.tc[2]); });
+    ch.template hidden<0>(bufA, d.ldh, a.tc[1], relu_to(bufB), [&] { ch.template prefetch_s<1>(a.tc[2]); });
     __syncthreads();
     STAMP(0, 6);
     // With the online critic's tiles made ahead its three layers are skipped; the first of them is
-    // prefetched by the layer before, so skipping is expressed as a layer without tiles (every load of it
-    // out of range), with the fields selected one by one (see csrc/fused.hip).
+    // prefetched by the layer before, so skipping is expressed as a layer without k-groups to load, with
+    // the field selected on its own (see csrc/fused.hip).
     LayerW32 after_tc = a.cf[0];
-    after_tc.ntiles = ahead_ok ? 0 : a.cf[0].ntiles;
+    after_tc.kg = ahead_ok ? 0 : a.cf[0].kg;
     ch.template split<1>(bufB, d.ldh, a.tc[2], [=](int r0, int col, f32x4 v) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) lg_t[(r0 + r) * nop + col] = v[r];
-    }, [&] { ch.template prefetch<0>(after_tc); });
+    }, [&] { ch.template prefetch_n<0>(after_tc); });
     if (!ahead_ok) {
         // ---- online critic: (s, a) -> logits, activations stashed for wgrad ----
         ch.template narrow<0>(xin, d.ldx, a.cf[0], [=](int r0, int col, f32x4 v) {
@@ -530,14 +537,14 @@ __global__ __launch_bounds__(64 * NW32) void critic_phase32_kernel(const CriticP
             for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
             put_lds4(bufC, ldh, r0, col, v);
             put_stash4(h1T, Bp, col, row0 + r0, v);
-        }, [&] { ch.template prefetch<1>(a.cf[1]); });
+        }, [&] { ch.template prefetch_h<1>(a.cf[1]); });
         __syncthreads();
         ch.template hidden<1>(bufC, d.ldh, a.cf[1], [=](int r0, int col, f32x4 v) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
             put_lds4(bufD, ldh, r0, col, v);
             put_stash4(h2T, Bp, col, row0 + r0, v);
-        }, [&] { ch.template prefetch<0>(a.cf[2]); });
+        }, [&] { ch.template prefetch_s<0>(a.cf[2]); });
         __syncthreads();
         ch.template split<0>(bufD, d.ldh, a.cf[2], [=](int r0, int col, f32x4 v) {
 #pragma unroll
@@ -546,7 +553,7 @@ __global__ __launch_bounds__(64 * NW32) void critic_phase32_kernel(const CriticP
     }
     // No prefetched registers are live where the two paths join: the first backward layer is fetched
     // here and lands while the loss rows are computed.
-    ch.template prefetch<1>(a.cb3);
+    ch.template prefetch_n<1>(a.cb3);
     critic_tail<MT, KSH, KSN>(a, ch, row0, lane, wave, lg_t, lg_o, dlg, sp, rs, bufC, bufD);
     STAMP_SPAN(0, 21, true);
 }
@@ -567,7 +574,7 @@ __device__ __forceinline__ void critic_ahead_role(const ActorPhaseArgs32& a, int
     float* lg = (float*)carve(M * d.nop * 4);
     float* red = (float*)carve((NW32 - 1) * MT * 256 * 4);
     Chain32<MT, KSH, KSN> ch(red);
-    ch.template prefetch<0>(a.cf[0]);
+    ch.template prefetch_n<0>(a.cf[0]);
     zero_tail(bufC, d.ldh, M, d.H);
     zero_tail(bufD, d.ldh, M, d.H);
     const RowSrc src = packed_src(a.pk, 0, 1);
@@ -581,7 +588,7 @@ __device__ __forceinline__ void critic_ahead_role(const ActorPhaseArgs32& a, int
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
         put_lds4(bufC, ldh, r0, col, v);
         put_stash4(h1T, Bp, col, row0 + r0, v);
-    }, [&] { ch.template prefetch<1>(a.cf[1]); });
+    }, [&] { ch.template prefetch_h<1>(a.cf[1]); });
     __syncthreads();
     copy16(a.ahead.h1 + (size_t)row0 * ldh, bufC, M * ldh * 4);
     ch.template hidden<1>(bufC, ldh, a.cf[1], [=](int r0, int col, f32x4 v) {
@@ -589,7 +596,7 @@ __device__ __forceinline__ void critic_ahead_role(const ActorPhaseArgs32& a, int
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
         put_lds4(bufD, ldh, r0, col, v);
         put_stash4(h2T, Bp, col, row0 + r0, v);
-    }, [&] { ch.template prefetch<0>(a.cf[2]); });
+    }, [&] { ch.template prefetch_s<0>(a.cf[2]); });
     __syncthreads();
     copy16(a.ahead.h2 + (size_t)row0 * ldh, bufD, M * ldh * 4);
     ch.template split<0>(bufD, ldh, a.cf[2], [=](int r0, int col, f32x4 v) {
@@ -649,7 +656,7 @@ __global__ __launch_bounds__(64 * NW32) void actor_phase32_kernel(const ActorPha
     float* lg_o = (float*)carve(M * d.nop * 4);
     float* red = (float*)carve((NW32 - 1) * MT * 256 * 4);
     Chain32<MT, KSH, KSN> ch(red);
-    ch.template prefetch<0>(a.cf[0]);
+    ch.template prefetch_n<0>(a.cf[0]);
     // ---- the actor forward pass of this tile was made alongside the critic phase ----
     copy16(xin, a.g_xin + (size_t)row0 * d.ldx, M * d.ldx * 4);
     copy16(bufA, a.g_h1 + (size_t)row0 * d.ldh, M * d.ldh * 4);
@@ -671,16 +678,16 @@ __global__ __launch_bounds__(64 * NW32) void actor_phase32_kernel(const ActorPha
         };
     };
     // ---- critic forward at (s, pi(s)) ----
-    ch.template narrow<0>(xin, d.ldx, a.cf[0], relu_to(bufC), [&] { ch.template prefetch<1>(a.cf[1]); });
+    ch.template narrow<0>(xin, d.ldx, a.cf[0], relu_to(bufC), [&] { ch.template prefetch_h<1>(a.cf[1]); });
     __syncthreads();
     STAMP(1, 1);
-    ch.template hidden<1>(bufC, ldh, a.cf[1], relu_to(bufD), [&] { ch.template prefetch<0>(a.cf[2]); });
+    ch.template hidden<1>(bufC, ldh, a.cf[1], relu_to(bufD), [&] { ch.template prefetch_s<0>(a.cf[2]); });
     __syncthreads();
     STAMP(1, 2);
     ch.template split<0>(bufD, ldh, a.cf[2], [=](int r0, int col, f32x4 v) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) lg_o[(r0 + r) * nop + col] = v[r];
-    }, [&] { ch.template prefetch<1>(a.cb3); });
+    }, [&] { ch.template prefetch_n<1>(a.cb3); });
     __syncthreads();
     STAMP(1, 3);
     // ---- actor loss: -mean Q ----
@@ -692,14 +699,14 @@ __global__ __launch_bounds__(64 * NW32) void actor_phase32_kernel(const ActorPha
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = bufD[(r0 + r) * ldh + col] > 0.f ? v[r] : 0.f;
         put_lds4(bufD, ldh, r0, col, v);
-    }, [&] { ch.template prefetch<0>(a.cb2); });
+    }, [&] { ch.template prefetch_h<0>(a.cb2); });
     __syncthreads();
     STAMP(1, 5);
     ch.template hidden<0>(bufD, ldh, a.cb2, [=](int r0, int col, f32x4 v) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = bufC[(r0 + r) * ldh + col] > 0.f ? v[r] : 0.f;
         put_lds4(bufC, ldh, r0, col, v);
-    }, [&] { ch.template prefetch<1>(a.cb1); });
+    }, [&] { ch.template prefetch_s<1>(a.cb1); });
     __syncthreads();
     STAMP(1, 6);
     ch.template split<1>(bufC, ldh, a.cb1, [=](int r0, int col, f32x4 v) {
@@ -710,7 +717,7 @@ __global__ __launch_bounds__(64 * NW32) void actor_phase32_kernel(const ActorPha
         }
         put_lds4(dab, lda_, r0, col, v);
         put_stash4(daT, Bp, col, row0 + r0, v);
-    }, [&] { ch.template prefetch<0>(a.ab3); });
+    }, [&] { ch.template prefetch_n<0>(a.ab3); });
     __syncthreads();
     STAMP(1, 7);
     // ---- actor backward ----
@@ -719,7 +726,7 @@ __global__ __launch_bounds__(64 * NW32) void actor_phase32_kernel(const ActorPha
         for (int r = 0; r < 4; ++r) v[r] = bufB[(r0 + r) * ldh + col] > 0.f ? v[r] : 0.f;
         put_lds4(bufB, ldh, r0, col, v);
         put_stash4(dh2T, Bp, col, row0 + r0, v);
-    }, [&] { ch.template prefetch<1>(a.ab2); });
+    }, [&] { ch.template prefetch_h<1>(a.ab2); });
     __syncthreads();
     STAMP(1, 8);
     ch.template hidden<1>(bufB, ldh, a.ab2, [=](int r0, int col, f32x4 v) {
@@ -791,7 +798,7 @@ static int check_layer32(const LayerW32& L, int kind, int ksh, int ksn, int ld) 
     if ((long long)L.ntiles * L.ks * CHUNK_BYTES >= (1ll << 31)) return -7;
     if (kind == 0) return (L.ksplit == 1 && L.nch == ksh) ? 0 : -10;
     if (kind == 1) return (L.ntiles == 1 && L.nch == split_nch(ksh) && L.ks >= ksh) ? 0 : -10;
-    return (L.ksplit == 1 && L.nch <= ksn) ? 0 : -10;
+    return (L.ksplit == 1 && L.nch <= ksn && L.kg >= 1 && L.kg <= KCH * L.nch) ? 0 : -10;
 }
 static int hidden_chunks(const PhaseDims& d) { return (d.H + 31) / 32; }
 static int max2i(int a, int b) { return a > b ? a : b; }

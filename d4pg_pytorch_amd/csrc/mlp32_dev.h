@@ -46,7 +46,8 @@ struct LayerW32 {
     int N;               // true number of outputs
     int ksplit;          // K-slices of the column tile; > 1 only for single-tile layers (N <= 64)
     int nch;             // chunks per unit = ks / ksplit
-    int pad_;
+    int kg;              // 16-byte k-groups of a unit that hold weights (= ceil(K / 4) for layers whose K is
+                         // not the hidden width: the rest of their chunks is padding and is not loaded)
 };
 // Work is dealt to the waves in units, one per wave: wave w of a layer with ksplit == 1 owns column
 // tile w; wave w of a single-tile layer owns K-slice w = chunks [w * n, (w + 1) * n), n = ks / ksplit.
@@ -57,7 +58,10 @@ struct Chunk32 {
 // The first PF chunks of a wave's unit of some layer, fetched while the layer before it still runs: the
 // stream of weight loads of a workgroup must not stop at a layer boundary (a layer is as fast as the
 // loads it keeps in flight; with one chunk fetched ahead a boundary cost ~0.6 us of idle load pipe).
-constexpr int PF32 = 2;
+#ifndef D4PG_PF32
+#define D4PG_PF32 2
+#endif
+constexpr int PF32 = D4PG_PF32;
 struct Pre32 {
     Chunk32 c[PF32];
     float bias;
@@ -69,7 +73,6 @@ struct WSrc32 {
     __amdgpu_buffer_rsrc_t rsrc;
     int voff;
     int soff;
-    int oob;       // an offset beyond the descriptor: loads from it return zeros without touching memory
 };
 __device__ __forceinline__ WSrc32 wsrc_of(const LayerW32& L, int wave, int lane) {
     const int bytes = L.ntiles * L.ks * CHUNK_BYTES;
@@ -81,16 +84,13 @@ __device__ __forceinline__ WSrc32 wsrc_of(const LayerW32& L, int wave, int lane)
     s.voff = (has && tile * 64 + lane < L.N) ? lane * 16 : bytes;
     // unit of wave w: chunks [w * nch, (w + 1) * nch) of the packed copy (nch = ks when the tiles are dealt out)
     s.soff = has ? wave * L.nch * CHUNK_BYTES : 0;
-    s.oob = bytes;
     return s;
 }
-// chunk `chunk` of the unit; `exists` false: a chunk beyond the unit (all lanes out of range)
-__device__ __forceinline__ Chunk32 load_chunk(const WSrc32& s, int chunk, bool exists = true) {
+__device__ __forceinline__ Chunk32 load_chunk(const WSrc32& s, int chunk) {
     Chunk32 c;
-    const int voff = exists ? s.voff : s.oob;
 #pragma unroll
     for (int g = 0; g < KCH; ++g)
-        c.b[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(s.rsrc, voff,
+        c.b[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(s.rsrc, s.voff,
                                                                                 s.soff + chunk * CHUNK_BYTES + g * 1024, 0));
     // The loads stay HERE in the instruction stream: left alone, the scheduler sinks every load to
     // just ahead of its first use (fewer live registers), which leaves one load in flight per wave.
@@ -98,14 +98,42 @@ __device__ __forceinline__ Chunk32 load_chunk(const WSrc32& s, int chunk, bool e
     return c;
 }
 
-// No branches: a wave without a unit loads zeros (out-of-range offsets) that nobody uses.
+// A wave-load costs the CU's load path 16 cycles whether its lanes are in range or not (a 400 x 400 layer
+// is 7 x 104 of them = 5.3 us, and that, not HBM or L2 bandwidth, is what a layer costs), so loads that
+// would only fetch padding are not issued: see the run-time variants below.
+
+// The first min(PF32, NCH) chunks of the wave's unit, unconditionally (a wave without a unit reads zeros
+// from out-of-range offsets): the consumer's load counting stays exact.
+template <int NCH>
 __device__ __forceinline__ Pre32 fetch_first(const LayerW32& L, int wave, int lane) {
     Pre32 t;
     const int col = (L.ksplit > 1 ? 0 : wave * 64) + lane;
     t.bias = L.bias[col < L.N ? col : 0];
     const WSrc32 src = wsrc_of(L, wave, lane);
 #pragma unroll
-    for (int j = 0; j < PF32; ++j) t.c[j] = load_chunk(src, j, j < L.nch);
+    for (int j = 0; j < PF32; ++j)
+        if (j < NCH) t.c[j] = load_chunk(src, j);
+    return t;
+}
+// Run-time variant for layers whose K is an input / action / atom count: only the k-groups that hold
+// weights are loaded (K = 8 is 2 of the 8 groups of a chunk).  Groups that are not loaded stay undefined
+// and are not multiplied.
+__device__ __forceinline__ void load_groups(Chunk32& c, const WSrc32& s, int chunk, int kg) {
+#pragma unroll
+    for (int g = 0; g < KCH; ++g)
+        if (chunk * KCH + g < kg)      // wave-uniform
+            c.b[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(s.rsrc, s.voff,
+                                                                                    s.soff + chunk * CHUNK_BYTES + g * 1024, 0));
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ Pre32 fetch_first_rt(const LayerW32& L, int wave, int lane) {
+    Pre32 t;
+    const int col = wave * 64 + lane;
+    t.bias = L.bias[col < L.N ? col : 0];
+    const WSrc32 src = wsrc_of(L, wave, lane);
+    const int kg = wave < L.ntiles ? L.kg : 0;
+#pragma unroll
+    for (int j = 0; j < PF32; ++j) load_groups(t.c[j], src, j, kg);
     return t;
 }
 
@@ -126,25 +154,43 @@ __device__ __forceinline__ void mma_chunk(const Chunk32& c, const float* Arow, i
     }
 }
 
+// the same for the first `ng` k-groups of a chunk only (run-time K)
+template <int MT>
+__device__ __forceinline__ void mma_groups(const Chunk32& c, int ng, const float* Arow, int lda, f32x4 (&acc)[MT][2]) {
+#pragma unroll
+    for (int g = 0; g < KCH; ++g) {
+        if (g < ng) {       // wave-uniform
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(Arow + mt * 4 * lda + 4 * g);
+                acc[mt][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[0], c.b[g][0], acc[mt][0], 0, 0, 0);
+                acc[mt][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[1], c.b[g][1], acc[mt][1], 0, 0, 0);
+                acc[mt][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[2], c.b[g][2], acc[mt][0], 0, 0, 0);
+                acc[mt][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[3], c.b[g][3], acc[mt][1], 0, 0, 0);
+            }
+        }
+    }
+}
+
 // The wave's unit has exactly NCH chunks (= L.nch, checked by the host), known at compile time:
 // the streaming loop is straight-line code with three chunk buffers in rotation (the chunk being
 // multiplied + two in flight; measured on one CU, a 400 x 400 layer on a 4-row tile: 6.1 us with
 // three, 6.5 with four, 6.9 with five buffers, 5.3 us for the loads alone, which is the rate at which
 // one CU is served by its L2).
-// RT = true: the unit has L.nch <= NCH chunks, known at run time (layers whose K is an input,
-// action or atom count).  All NCH chunks are loaded up front; the ones beyond L.nch use an
-// out-of-range offset (zeros, no memory traffic) and are not multiplied.
+// RT = true: the unit has L.kg <= 8 * NCH k-groups, known at run time (layers whose K is an input,
+// action or atom count).  Everything is loaded up front, group by group, and only what was loaded is
+// multiplied; `pre` follows the multiplications (the waits of this variant are for all loads in flight).
 //
 // epi(row0, col, v): v = rows row0 .. row0 + 3 of output column col (bias added), col < L.N.
 // A   : LDS fp32 [4 * MT][lda], columns up to 32 * L.ks readable (zero beyond the true K)
-// t   : the first PF32 chunks of this wave's unit (fetch_first, issued by the layer before)
+// t   : the first PF32 chunks of this wave's unit (fetch_first*, issued by the layer before)
 // red : LDS scratch for the K-slice partial sums, (NW - 1) * MT * 256 floats
 // One unit per wave, so max(ntiles, ksplit) <= NW.  With ksplit > 1 the slices of the tile meet
 // through `red` behind one workgroup barrier, and wave 0 finishes the tile (fixed summation order).
-// `pre` issues the loads of the NEXT layer's first chunks.  It is called at ONE place, right behind
-// this layer's own last load, so that the two streams join without a gap.  There is no branch around
-// the streaming code: every load is unconditional (so the compiler's count of the loads in flight is
-// exact) and a wave without a unit multiplies the zeros it loaded, on a SIMD that would otherwise idle.
+// `pre` issues the loads of the NEXT layer's first chunks, right behind this layer's own last load, so
+// that the two streams join without a gap.  The streaming code of a wave with a unit is straight-line
+// (every load unconditional, so the compiler's count of the loads in flight is exact); a wave without a
+// unit only runs `pre`.
 template <int NW, int MT, int NCH, bool RT, typename F, typename P>
 __device__ __forceinline__ void layer32(Pre32& t, const float* A, int lda, const LayerW32& L, float* red, F&& epi,
                                         P&& pre) {
@@ -153,35 +199,47 @@ __device__ __forceinline__ void layer32(Pre32& t, const float* A, int lda, const
     const bool split = L.ksplit > 1;
     const bool has = wave < (split ? L.ksplit : L.ntiles);
     const int col = (split ? 0 : wave * 64) + lane;
-    const int slice = (split && has) ? wave : 0;
+    const int slice = split ? wave : 0;
     f32x4 acc[MT][2];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt][0] = acc[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // `pre` has ONE call site, between the two halves of the streaming code (a second call site makes the
+    // compiler route every kernel argument through scratch memory).
     const WSrc32 src = wsrc_of(L, wave, lane);
     const float* Al = A + (lane & 3) * lda + slice * L.nch * 32;
     constexpr int RING = RT ? NCH : (NCH < 3 ? NCH : 3);
-    constexpr int HAVE = PF32 < RING ? PF32 : RING;         // chunks that arrive in `t`
+    constexpr int HAVE = PF32 < RING ? PF32 : RING;                       // chunks that arrive in `t`
+    constexpr int PRE_AT = (RT || NCH <= RING) ? (RT ? NCH : 0) : NCH - RING;   // chunks multiplied ahead of `pre`
     Chunk32 ring[RING];
+    if (has) {
 #pragma unroll
-    for (int c = 0; c < HAVE; ++c) ring[c] = t.c[c];
+        for (int c = 0; c < HAVE; ++c) ring[c] = t.c[c];
+        if constexpr (RT) {
 #pragma unroll
-    for (int c = HAVE; c < RING; ++c) ring[c] = load_chunk(src, c, !RT || c < L.nch);
-    constexpr int PRE_AT = (RT || NCH <= RING) ? 0 : NCH - RING;      // behind the refill that is this layer's last load
+            for (int c = HAVE; c < RING; ++c) load_groups(ring[c], src, c, L.kg);
+        } else {
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        if constexpr (PRE_AT == 0) {
-            if (c == 0) pre();
+            for (int c = HAVE; c < RING; ++c) ring[c] = load_chunk(src, c);
         }
-        if (!RT || c < L.nch) mma_chunk<MT>(ring[c % RING], Al + c * 32, lda, acc);
-        if constexpr (!RT) {
-            if (c + RING < NCH) ring[c % RING] = load_chunk(src, c + RING);
-        }
-        if constexpr (PRE_AT > 0) {
-            if (c + 1 == PRE_AT) pre();
+#pragma unroll
+        for (int c = 0; c < PRE_AT; ++c) {
+            if constexpr (RT) {
+                mma_groups<MT>(ring[c], L.kg - c * KCH, Al + c * 32, lda, acc);
+            } else {
+                mma_chunk<MT>(ring[c % RING], Al + c * 32, lda, acc);
+                if (c + RING < NCH) ring[c % RING] = load_chunk(src, c + RING);      // the last of them is this layer's last load
+            }
         }
     }
+    pre();
+    if (has) {
+        if constexpr (!RT) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[mt][0] += acc[mt][1];
+            for (int c = PRE_AT; c < NCH; ++c) mma_chunk<MT>(ring[c % RING], Al + c * 32, lda, acc);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][0] += acc[mt][1];
+    }
     if (split) {       // workgroup-uniform
         if (has && slice != 0) {
 #pragma unroll

@@ -117,6 +117,7 @@ class HipCoreF32(HipCoreBf16):
         L.W = shadow[p.off:].data_ptr()
         L.bias = self.zero_bias.data_ptr() if back else flat[slot.b_off:].data_ptr()
         L.ks, L.ntiles, L.N, L.ksplit, L.nch = p.ks, p.ntiles, p.N, p.ksplit, p.nch
+        L.kg = (p.K + 3) // 4 if p.ksplit == 1 else p.nch * 8       # 16-byte k-groups that hold weights
         return L
 
     def _wgrad(self, triples, opt=None, sample_next: bool = False) -> None:

@@ -222,7 +222,7 @@ class WgradGroup(C.Structure):
 # ---- fused fp32 pipeline (csrc/fused32.hip) ----
 class LayerW32(C.Structure):
     _fields_ = [("W", vp), ("bias", vp), ("ks", C.c_int), ("ntiles", C.c_int), ("N", C.c_int), ("ksplit", C.c_int),
-                ("nch", C.c_int), ("pad_", C.c_int)]
+                ("nch", C.c_int), ("kg", C.c_int)]
 
 
 class ActorFwd32(C.Structure):
