@@ -35,10 +35,14 @@ Data-parallel modes (``--dp-mode``, N > 1):
                   (``dp_mode: auto``: replicated up to a global batch of 8192 rows; gradient all-reduce beyond), the other one is reported as
                   ``grad_allreduce_value`` / ``replicated_value``.
 Both make the update a single learner would make on the concatenated global batch.
-For N > 1 every rank also times the SAME configuration on its own GPU alone (no
-collectives, batch 256): ``single_gpu_same_config_value`` is what the N-GPU ``value`` should
-be divided by (and by N) for a like-for-like scaling efficiency, since the N == 1 default
-is the LunarLander shape.
+For N > 1 every rank also times two single-GPU runs without collectives on its own GPU:
+``single_gpu_same_config_value`` (the per-rank configuration, batch 256: what the N-GPU ``value``
+divided by N compares with, since the N == 1 default is the LunarLander shape) and
+``single_gpu_global_batch_value`` (ONE GPU running the job's global batch of N x 256 rows per update,
+in the same batch-256 units).  ``speedup_vs_single_gpu_global_batch`` = ``value`` over the latter is
+what the extra GPUs buy the LEARNER; an update of these 400-wide MLPs is a latency-bound chain of small
+layers, so at small per-rank batches that ratio is near or below 1 and the extra GPUs pay for themselves
+through replay capacity, ingest bandwidth and exploiters, not through learner arithmetic.
 
 For N > 1 the driver launches this file under torch.distributed.run (one rank
 per GPU).  Rank 0 prints ONE JSON line.  ``value`` aggregates all ranks:
@@ -234,14 +238,27 @@ def main() -> None:
             return core, t
 
         if world > 1 or args.dp_selftest:
-            real_comm, comm = comm, LocalComm()          # this rank alone: no collectives
+            # What ONE GPU does alone, no collectives: (a) the per-rank configuration (batch B) and (b) the
+            # job's GLOBAL batch (world x B rows per update).  (b) is the honest denominator for a
+            # data-parallel learner: N GPUs are worth having for the learner only if the N-GPU job beats it.
+            real_comm, comm = comm, LocalComm()
             try:
                 _, dt_1 = run_grad_allreduce()
                 extra["single_gpu_same_config_value"] = round(args.steps / dt_1, 2)
             except Exception as exc:
                 extra["single_gpu_same_config_error"] = repr(exc)[:200]
-            comm = real_comm
             torch.cuda.empty_cache()
+            if world > 1:
+                cfg_rank, cfg = cfg, dict(cfg, batch_size=args.batch * world)
+                try:
+                    _, dt_g = run_grad_allreduce()
+                    extra["single_gpu_global_batch_value"] = round(args.steps / dt_g * world, 2)
+                    extra["single_gpu_global_batch_ms_per_step"] = round(1000.0 * dt_g / args.steps, 5)
+                except Exception as exc:
+                    extra["single_gpu_global_batch_error"] = repr(exc)[:200]
+                cfg = cfg_rank
+                torch.cuda.empty_cache()
+            comm = real_comm
         if world == 1 and not args.dp_selftest:
             core, dt = run_grad_allreduce()
             if args.dtype == "fp32" and not args.no_bf16 and not args.layers:
@@ -313,6 +330,10 @@ def main() -> None:
                            "grad_allreduce": " (gradient all-reduce)"}[dp_mode]},
         }
         out.update(extra)
+        if "single_gpu_global_batch_value" in extra:
+            out["speedup_vs_single_gpu_global_batch"] = round(value / extra["single_gpu_global_batch_value"], 3)
+        if dp_mode == "grad_allreduce":
+            out["grad_allreduce_in_graph"] = bool(getattr(core, "_sync_in_graph", lambda: False)())
         print(json.dumps(out), flush=True)
     comm.close()
 

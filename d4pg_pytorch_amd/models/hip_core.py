@@ -307,13 +307,34 @@ class HipCore(CoreBase):
             self._segments_cache[source] = self._build_segments(source)
         return self._segments_cache[source]
 
+    def _sync_in_graph(self) -> bool:
+        """Can the gradient exchange be captured into the update's graph?  True for collectives that are
+        enqueued on the stream (RCCL); host-side exchanges (the in-process test fake, gloo staging) and a
+        capture that failed once keep the update cut into three graphs with the exchange between them."""
+        return bool(getattr(self.grad_sync, "capturable", False)) and not getattr(self, "_dp_capture_failed", False)
+
     def _run(self, source: str, reps: int = 1) -> None:
-        """Enqueue ``reps`` consecutive updates from ``source``.  Without gradient exchange they
-        are ONE graph (a graph launch costs ~8 us of idle GPU between two replays, so a source
-        that holds several batches is replayed several updates at a time)."""
+        """Enqueue ``reps`` consecutive updates from ``source`` as ONE graph replay (a graph launch costs
+        ~8 us of idle GPU between two replays, so a source that holds several batches is replayed several
+        updates at a time).  With data-parallel learners the two gradient all-reduces of every update are
+        nodes of that same graph when the collective library can be captured (RCCL): nothing returns to
+        the host between the critic phase of the first and the optimiser of the last update."""
         segs = self._segments(source)
         sync = self.grad_sync
         lay = self.layout
+        if sync is not None and self.use_graph and self._sync_in_graph():
+            key = source + "/dp1g" + (f"/x{reps}" if reps > 1 else "")
+            if key not in self._graphs:
+                try:
+                    self._graphs[key] = self._capture(self._with_sync(segs), fused=True, reps=reps)
+                except Exception as exc:      # the collective refused capture: fall back for good
+                    import warnings
+                    warnings.warn(f"gradient all-reduce could not be captured into the update graph ({exc!r}); "
+                                  "using three graph segments with host-issued collectives")
+                    self._dp_capture_failed = True
+            if key in self._graphs:
+                self._graphs[key][0].replay()
+                return
         if reps > 1 and sync is not None and self.use_graph:
             for _ in range(reps):          # gradient exchange between the graph segments: one update at a time
                 self._run(source, 1)
@@ -341,10 +362,27 @@ class HipCore(CoreBase):
             sync(self.grad[lay.actor.base: lay.actor.base + lay.actor.numel])
             graphs[2].replay()
 
+    def _with_sync(self, segs):
+        """The three segments of an update with the two gradient exchanges between them, as one list."""
+        lay, sync = self.layout, self.grad_sync
+        cr = slice(lay.critic.base, lay.critic.base + lay.critic.numel)
+        ac = slice(lay.actor.base, lay.actor.base + lay.actor.numel)
+        return [segs[0], lambda: sync(self.grad[cr]), segs[1], lambda: sync(self.grad[ac]), segs[2]]
+
     def ensure_captured(self, source: str, reps: int = 1) -> None:
         """Capture the graph ``_run(source, reps)`` would replay, if it does not exist yet."""
         sync = self.grad_sync
-        if not self.use_graph or (reps > 1 and sync is not None):
+        if not self.use_graph:
+            return
+        if sync is not None and self._sync_in_graph():
+            key = source + "/dp1g" + (f"/x{reps}" if reps > 1 else "")
+            if key not in self._graphs:
+                try:
+                    self._graphs[key] = self._capture(self._with_sync(self._segments(source)), fused=True, reps=reps)
+                except Exception:
+                    self._dp_capture_failed = True
+            return
+        if reps > 1 and sync is not None:
             return
         key = source + ("/dp" if sync is not None else "") + (f"/x{reps}" if reps > 1 else "")
         if key not in self._graphs:
@@ -373,7 +411,9 @@ class HipCore(CoreBase):
         try:
             for grp in groups:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                # thread_local: other threads (the collective library's watchdog, the ring ingest thread) may
+                # make HIP calls while this thread captures
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     for f in grp:
                         f()
                 graphs.append(g)

@@ -215,7 +215,13 @@ def attach_data_parallel(core, comm: Comm) -> None:
         st = core.read_dev_state()
         core._write_dev_state(step=core.step, seed=(st.seed + 0x9E3779B97F4A7C15 * (comm.rank + 1)),
                               keep_replay=True)
-        core.grad_sync = lambda g: comm.all_reduce_sum_(g)
+        def sync_sum(g: torch.Tensor) -> None:
+            comm.all_reduce_sum_(g)
+        # RCCL collectives are stream-ordered: the update graph captures them (HipCore._run); anything that
+        # goes through the host (gloo staging, the in-process fake) stays between graph segments
+        sync_sum.capturable = isinstance(comm, TorchDistComm) and comm.backend == "nccl" and \
+            not os.environ.get("D4PG_DP_SEGMENTED")
+        core.grad_sync = sync_sum
     else:
         inv = 1.0 / comm.world
 

@@ -153,8 +153,10 @@ class ReplicatedDP:
         restores the state), so that none of them falls into a timed or latency-sensitive region."""
         self._precaptured = True
         core = self.core
-        if not getattr(core, "use_graph", False) or core.grad_sync is not None:
+        if not getattr(core, "use_graph", False):
             return
+        if core.grad_sync is not None and not core._sync_in_graph():
+            return          # host-issued gradient exchange: the update stays cut into per-update graph segments
         if self.n == 0 and not getattr(self, "_primed_by_inspection", False):
             # the throw-away updates read chunk 0: draw it (and chunk 1, as update() would) first
             self._draw_chunk(0)
