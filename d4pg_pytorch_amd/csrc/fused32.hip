@@ -740,6 +740,63 @@ __global__ __launch_bounds__(64 * NW32) void actor_phase32_kernel(const ActorPha
     STAMP(1, 9);
 }
 
+// ---- batched policy inference: a = tanh(actor(obs)) for E rows, ONE launch ------------------------------
+// What an agent needs per environment step (models/d4pg/networks.py:78-81 is six kernels, an H2D and a D2H
+// copy per step and environment): the three actor layers on a tile of 4 * MT environments per workgroup,
+// weights from packed fp32 copies (csrc/mlp32_dev.h), activations in LDS.  Used by GPU exploiters /
+// explorers (actors/gpu_actor.py) and by the device-resident rollout (actors/gpu_rollout.py).
+struct ActorInferArgs32 {
+    LayerW32 l[3];
+    const float* obs;     // [E][ld_obs], first S columns are the observation
+    float* act;           // [E][ld_act], first A columns are written
+    int E, S, A, H;
+    int ld_obs, ld_act, ldx, ldh;
+    float action_scale;
+    int pad_;
+};
+
+template <int MT, int KSH, int KSN>
+__global__ __launch_bounds__(64 * NW32) void actor_infer32_kernel(const ActorInferArgs32 a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int M = 4 * MT;
+    const int row0 = blockIdx.x * M;
+    int off = 0;
+    auto carve = [&](int bytes) { char* p = smem + off; off += (bytes + 15) & ~15; return p; };
+    float* xin = (float*)carve(M * a.ldx * 4);
+    float* bufA = (float*)carve(M * a.ldh * 4);
+    float* bufB = (float*)carve(M * a.ldh * 4);
+    float* red = (float*)carve((NW32 - 1) * MT * 256 * 4);
+    Chain32<MT, KSH, KSN> ch(red);
+    ch.template prefetch_n<0>(a.l[0]);
+    const int ldh = a.ldh, ldx = a.ldx, E = a.E, ld_act = a.ld_act;
+    float* const act = a.act;
+    const float scale = a.action_scale;
+    zero_tail(bufA, ldh, M, a.H);
+    zero_tail(bufB, ldh, M, a.H);
+    for (int i = threadIdx.x; i < M * ldx; i += blockDim.x) {
+        const int r = i / ldx, c = i - r * ldx;
+        xin[i] = (c < a.S && row0 + r < E) ? a.obs[(size_t)(row0 + r) * a.ld_obs + c] : 0.f;
+    }
+    __syncthreads();
+    ch.template narrow<0>(xin, ldx, a.l[0], [=](int r0, int col, f32x4 v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        put_lds4(bufA, ldh, r0, col, v);
+    }, [&] { ch.template prefetch_h<1>(a.l[1]); });
+    __syncthreads();
+    ch.template hidden<1>(bufA, ldh, a.l[1], [=](int r0, int col, f32x4 v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        put_lds4(bufB, ldh, r0, col, v);
+    }, [&] { ch.template prefetch_s<0>(a.l[2]); });
+    __syncthreads();
+    ch.template split<0>(bufB, ldh, a.l[2], [=](int r0, int col, f32x4 v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (row0 + r0 + r < E) act[(size_t)(row0 + r0 + r) * ld_act + col] = fast_tanh(v[r]) * scale;
+    }, [] {});
+}
+
 // ---- host launchers -----------------------------------------------------------------------------
 static int lds_bytes_critic32(const PhaseDims& d, int M, int mt) {
     auto al = [](int b) { return (b + 15) & ~15; };
@@ -767,11 +824,13 @@ static int lds_bytes_actor32(const PhaseDims& d, int M, int mt) {
         return launch_phase(KERNEL<4, KSH, 4>, *a, grid, NW32, lds, stream);                               \
     }
 D4PG_PHASE32_LAUNCHER(launch_critic32_ksh, critic_phase32_kernel, CriticPhaseArgs32)
+D4PG_PHASE32_LAUNCHER(launch_infer32_ksh, actor_infer32_kernel, ActorInferArgs32)
 D4PG_PHASE32_LAUNCHER(launch_actor32_ksh, actor_phase32_kernel, ActorPhaseArgs32)
 
 #define D4PG_PHASE32_INSTANCES(PREFIX, KSHV)                                                                   \
     PREFIX template int launch_critic32_ksh<KSHV>(const CriticPhaseArgs32*, int, int, int, int, hipStream_t);  \
-    PREFIX template int launch_actor32_ksh<KSHV>(const ActorPhaseArgs32*, int, int, int, int, hipStream_t);
+    PREFIX template int launch_actor32_ksh<KSHV>(const ActorPhaseArgs32*, int, int, int, int, hipStream_t);   \
+    PREFIX template int launch_infer32_ksh<KSHV>(const ActorInferArgs32*, int, int, int, int, hipStream_t);
 #if D4PG_KSH_PART == -1          // main unit: the widths live in their own objects
 D4PG_PHASE32_INSTANCES(extern, 13)
 D4PG_PHASE32_INSTANCES(extern, 4)
@@ -886,6 +945,33 @@ D4PG_API int d4pg_actor_phase32(const ActorPhaseArgs32* a, int mt, hipStream_t s
     const int extra_blocks = (a->tree.n > 0 ? 1 : 0) + n_ahead + n_warmers32(d, M);
     DISPATCH_PHASE32(launch_actor32_ksh, lds_bytes_actor32)
 }
+
+
+// Batched actor inference (one launch).  mt: rows per workgroup / 4 (1, 2 or 4).
+D4PG_API int d4pg_actor_infer32(const ActorInferArgs32* a, int mt, hipStream_t stream) {
+    if (mt != 1 && mt != 2 && mt != 4) return -9;
+    if (a->E < 1 || a->S < 1 || a->A < 1 || a->A > 64 || a->obs == nullptr || a->act == nullptr) return -1;
+    if ((a->ldx & 3) || (a->ldh & 3) || a->ldx < a->S || a->ld_obs < a->S || a->ld_act < a->A) return -3;
+    const int M = 4 * mt;
+    const int ksh = (a->H + 31) / 32;
+    const int ksn = a->l[0].nch <= 2 ? 2 : 4;
+    if (int rc = check_layer32(a->l[0], 2, ksh, ksn, a->ldx)) return rc;
+    if (int rc = check_layer32(a->l[1], 0, ksh, ksn, a->ldh)) return rc;
+    if (int rc = check_layer32(a->l[2], 1, ksh, ksn, a->ldh)) return rc;
+    auto al = [](int b) { return (b + 15) & ~15; };
+    const int lds = al(M * a->ldx * 4) + 2 * al(M * a->ldh * 4) + al((NW32 - 1) * mt * 256 * 4);
+    const int grid = (a->E + M - 1) / M;
+#ifdef D4PG_STAMPS
+    if (ksh == 13) return launch_infer32_ksh<13>(a, mt, ksn, grid, lds, stream);
+    return -10;
+#else
+    if (ksh == 13) return launch_infer32_ksh<13>(a, mt, ksn, grid, lds, stream);
+    if (ksh == 4) return launch_infer32_ksh<4>(a, mt, ksn, grid, lds, stream);
+    if (ksh == 8) return launch_infer32_ksh<8>(a, mt, ksn, grid, lds, stream);
+    return -10;
+#endif
+}
+D4PG_API int d4pg_sizeof_ActorInferArgs32() { return (int)sizeof(ActorInferArgs32); }
 
 D4PG_API int d4pg_phase32_lds_bytes(const PhaseDims* d, int mt, int actor) {
     return actor ? lds_bytes_actor32(*d, 4 * mt, mt) : lds_bytes_critic32(*d, 4 * mt, mt);

@@ -1,0 +1,198 @@
+// Device-resident rollouts and weight hand-off between processes on one GPU (gfx950).
+//
+//  pack_actor32_kernel   : flat actor parameters (the learner's fp32 master layout) -> the packed fp32
+//                          copies the inference kernel streams (csrc/mlp32_dev.h), device to device;
+//                          the source may be another process's memory opened through HIP IPC
+//  pendulum_step_kernel  : E inverted pendulums (the dynamics of gym's Pendulum-v0, envs/pendulum.py)
+//                          advanced one step on the device, with time-limit resets from a Philox stream
+//  rollout_rows_kernel   : a [T, E] rollout segment + its n-step targets (csrc/nstep.hip) -> replay rows
+//                          [s | a | R | done | gamma^k | s'] ready for replay_insert, no host hop
+//  d4pg_ipc_*            : hipIpc memory handles, so that an agent process reads the learner's weights in
+//                          place (what torch's share_memory() gives the reference on CUDA,
+//                          models/d4pg/engine.py:129-144)
+#include <string.h>
+
+#include "common.h"
+#include "mlp32_dev.h"
+
+struct PackMat32 {
+    long long src_off;     // W[out][ld] inside the flat source (floats)
+    long long bias_off;    // bias[out] inside the flat source
+    long long dst_off;     // packed copy inside dst (floats)
+    long long dst_bias;    // bias copy inside dst
+    int out_dim, in_dim, ld, ks;
+};
+struct PackActorArgs32 {
+    const float* src;
+    float* dst;
+    PackMat32 m[3];
+};
+
+__global__ __launch_bounds__(256) void pack_actor32_kernel(const PackActorArgs32 a) {
+    const PackMat32& m = a.m[blockIdx.y];
+    const long long n = (long long)m.out_dim * m.in_dim;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int o = (int)(i / m.in_dim), k = (int)(i - (long long)o * m.in_dim);
+        a.dst[m.dst_off + packed32_off(o, k, m.ks)] = a.src[m.src_off + (long long)o * m.ld + k];
+        if (k == 0) a.dst[m.dst_bias + o] = a.src[m.bias_off + o];
+    }
+}
+D4PG_API int d4pg_pack_actor32(const PackActorArgs32* a, hipStream_t stream) {
+    if (a->src == nullptr || a->dst == nullptr) return -1;
+    for (int i = 0; i < 3; ++i)
+        if (a->m[i].out_dim < 1 || a->m[i].in_dim < 1 || a->m[i].ld < a->m[i].in_dim || a->m[i].ks * 32 < a->m[i].in_dim) return -2;
+    hipLaunchKernelGGL(pack_actor32_kernel, dim3(160, 3), dim3(256), 0, stream, *a);
+    return (int)hipGetLastError();
+}
+D4PG_API int d4pg_sizeof_PackActorArgs32() { return (int)sizeof(PackActorArgs32); }
+
+// ---------------------------------------------------------------------------------------------------
+struct PendulumArgs {
+    float* theta;            // [E] state, updated in place
+    float* theta_dot;        // [E]
+    int* t;                  // [E] steps into the episode
+    float* ep_return;        // [E] running (unscaled) episode return
+    const float* action;     // [E][ld_act] torque in column 0
+    float* obs;              // [E][3]  observation the policy sees NEXT (after a reset where one happened)
+    float* next_obs;         // [E][3]  observation that followed the action (the transition's s')
+    float* reward;           // [E]     scaled reward (reward / reward_scale)
+    float* done;             // [E]     terminal flag (a pendulum never terminates: 0)
+    float* trunc;            // [E]     1 where the time limit ended the episode at this step (limit_terminal == 0)
+    float* noise;            // [E][ld_act] exploration-noise state, zeroed where an episode ends; or null
+    double* stats;           // [2] sum of finished episode returns, number of finished episodes
+    unsigned long long* counter;   // device counter: one increment per call (Philox stream position)
+    unsigned long long seed;
+    int E, ld_act, time_limit, init;     // init: 1 = reset every environment instead of stepping
+    float reward_scale;
+    int limit_terminal;      // 1: the time limit is reported as done (gym's old 4-tuple API, env/env_wrapper.py:17-19)
+};
+
+__global__ __launch_bounds__(256) void pendulum_step_kernel(const PendulumArgs a) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long ctr = *a.counter;
+    if (e >= a.E) return;
+    const float max_speed = 8.f, max_torque = 2.f, dt = 0.05f, g = 10.f, m = 1.f, l = 1.f, pi = 3.14159265358979f;
+    float th = a.theta[e], thd = a.theta_dot[e];
+    int t = a.t[e];
+    bool reset = a.init != 0;
+    if (!a.init) {
+        const float u = fminf(max_torque, fmaxf(-max_torque, a.action[(size_t)e * a.ld_act]));
+        float ang = fmodf(th + pi, 2.f * pi);
+        if (ang < 0.f) ang += 2.f * pi;
+        ang -= pi;
+        const float cost = ang * ang + 0.1f * thd * thd + 0.001f * u * u;
+        const float nthd = thd + (-3.f * g / (2.f * l) * sinf(th + pi) + 3.f / (m * l * l) * u) * dt;
+        th = th + nthd * dt;
+        thd = fminf(max_speed, fmaxf(-max_speed, nthd));
+        t += 1;
+        a.next_obs[e * 3 + 0] = cosf(th);
+        a.next_obs[e * 3 + 1] = sinf(th);
+        a.next_obs[e * 3 + 2] = thd;
+        a.reward[e] = -cost / a.reward_scale;
+        const float ret = a.ep_return[e] - cost;
+        reset = a.time_limit > 0 && t >= a.time_limit;
+        a.done[e] = reset && a.limit_terminal ? 1.f : 0.f;
+        a.trunc[e] = reset && !a.limit_terminal ? 1.f : 0.f;
+        if (reset) {
+            atomicAdd(&a.stats[0], (double)ret);
+            atomicAdd(&a.stats[1], 1.0);
+        }
+        a.ep_return[e] = reset ? 0.f : ret;
+    }
+    if (reset) {
+        uint32_t r[4];
+        philox4x32((uint32_t)e, (uint32_t)ctr, (uint32_t)(ctr >> 32), 0x9E3779B9u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), r);
+        th = ((float)(r[0] >> 8) * (1.0f / 16777216.0f) * 2.f - 1.f) * pi;
+        thd = (float)(r[1] >> 8) * (1.0f / 16777216.0f) * 2.f - 1.f;
+        t = 0;
+        if (a.init) a.ep_return[e] = 0.f;
+        if (a.noise != nullptr)
+            for (int j = 0; j < a.ld_act; ++j) a.noise[(size_t)e * a.ld_act + j] = 0.f;
+    }
+    a.theta[e] = th;
+    a.theta_dot[e] = thd;
+    a.t[e] = t;
+    a.obs[e * 3 + 0] = cosf(th);
+    a.obs[e * 3 + 1] = sinf(th);
+    a.obs[e * 3 + 2] = thd;
+}
+__global__ void rollout_counter_kernel(unsigned long long* c) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *c += 1;
+}
+D4PG_API int d4pg_pendulum_step(const PendulumArgs* a, hipStream_t stream) {
+    if (a->E < 1 || a->theta == nullptr || a->obs == nullptr || a->counter == nullptr) return -1;
+    if (!a->init && (a->action == nullptr || a->next_obs == nullptr || a->reward == nullptr || a->done == nullptr ||
+                     a->trunc == nullptr || a->stats == nullptr || a->ld_act < 1))
+        return -2;
+    hipLaunchKernelGGL(pendulum_step_kernel, dim3((a->E + 255) / 256), dim3(256), 0, stream, *a);
+    hipLaunchKernelGGL(rollout_counter_kernel, dim3(1), dim3(64), 0, stream, a->counter);
+    return (int)hipGetLastError();
+}
+D4PG_API int d4pg_sizeof_PendulumArgs() { return (int)sizeof(PendulumArgs); }
+
+// ---------------------------------------------------------------------------------------------------
+struct RolloutRowsArgs {
+    const float* obs;        // [T][E][S]   observation the action was chosen from
+    const float* act;        // [T][E][ld_act]
+    const float* next_obs;   // [T][E][S]   observation that followed (before any reset)
+    const float* R;          // [T][E] n-step return          (csrc/nstep.hip)
+    const float* gk;         // [T][E] gamma^k
+    const int* nxt;          // [T][E] step whose next_obs is the bootstrap state
+    const float* d;          // [T][E] terminal flag of that step
+    float* rows;             // [T * E][row_ld]
+    int T, E, S, A, ld_act, row_ld;
+};
+__global__ __launch_bounds__(256) void rollout_rows_kernel(const RolloutRowsArgs a) {
+    const int W = 2 * a.S + a.A + 3;
+    const long long total = (long long)a.T * a.E * W;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long te = i / W;
+        const int c = (int)(i - te * W);
+        const int t = (int)(te / a.E), e = (int)(te - (long long)t * a.E);
+        float v;
+        if (c < a.S) v = a.obs[te * a.S + c];
+        else if (c < a.S + a.A) v = a.act[te * a.ld_act + (c - a.S)];
+        else if (c == a.S + a.A) v = a.R[te];
+        else if (c == a.S + a.A + 1) v = a.d[te];
+        else if (c == a.S + a.A + 2) v = a.gk[te];
+        else v = a.next_obs[((long long)a.nxt[te] * a.E + e) * a.S + (c - a.S - a.A - 3)];
+        a.rows[te * a.row_ld + c] = v;
+    }
+}
+D4PG_API int d4pg_rollout_rows(const RolloutRowsArgs* a, hipStream_t stream) {
+    if (a->T < 1 || a->E < 1 || a->S < 1 || a->A < 1 || a->row_ld < 2 * a->S + a->A + 3 || a->ld_act < a->A) return -1;
+    if (a->obs == nullptr || a->act == nullptr || a->next_obs == nullptr || a->R == nullptr || a->gk == nullptr ||
+        a->nxt == nullptr || a->d == nullptr || a->rows == nullptr)
+        return -2;
+    const long long total = (long long)a->T * a->E * (2 * a->S + a->A + 3);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(rollout_rows_kernel, dim3(blocks), dim3(256), 0, stream, *a);
+    return (int)hipGetLastError();
+}
+D4PG_API int d4pg_sizeof_RolloutRowsArgs() { return (int)sizeof(RolloutRowsArgs); }
+
+// ---------------------------------------------------------------------------------------------------
+// Inter-process sharing of a device buffer.  The exporting process allocates with d4pg_ipc_alloc (a
+// dedicated hipMalloc allocation, so the handle names exactly this buffer) and passes the 64-byte handle
+// on; any other process on the machine maps the same memory with d4pg_ipc_open.
+D4PG_API int d4pg_ipc_alloc(size_t bytes, void** out, unsigned char* handle64) {
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
+    HIP_CHECK_RET(hipMalloc(out, bytes));
+    HIP_CHECK_RET(hipMemset(*out, 0, bytes));
+    hipIpcMemHandle_t h;
+    HIP_CHECK_RET(hipIpcGetMemHandle(&h, *out));
+    memcpy(handle64, &h, 64);
+    return 0;
+}
+D4PG_API int d4pg_ipc_open(const unsigned char* handle64, void** out) {
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle64, 64);
+    HIP_CHECK_RET(hipIpcOpenMemHandle(out, h, hipIpcMemLazyEnablePeerAccess));
+    return 0;
+}
+D4PG_API int d4pg_ipc_close(void* p) { return (int)hipIpcCloseMemHandle(p); }
+D4PG_API int d4pg_ipc_free(void* p) { return (int)hipFree(p); }
+D4PG_API int d4pg_memcpy_d2d_async(void* dst, const void* src, size_t bytes, hipStream_t stream) {
+    return (int)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream);
+}

@@ -260,6 +260,34 @@ class WgradGroup32(C.Structure):
                 ("pad_", C.c_int), ("opt", WgradAdam), ("smp", vp), ("smp_rows", C.c_int), ("pad2_", C.c_int)]
 
 
+class ActorInferArgs32(C.Structure):
+    _fields_ = [("l", LayerW32 * 3), ("obs", vp), ("act", vp), ("E", C.c_int), ("S", C.c_int), ("A", C.c_int),
+                ("H", C.c_int), ("ld_obs", C.c_int), ("ld_act", C.c_int), ("ldx", C.c_int), ("ldh", C.c_int),
+                ("action_scale", C.c_float), ("pad_", C.c_int)]
+
+
+# ---- device-resident rollouts, weight hand-off (csrc/rollout.hip) ----
+class PackMat32(C.Structure):
+    _fields_ = [("src_off", C.c_longlong), ("bias_off", C.c_longlong), ("dst_off", C.c_longlong),
+                ("dst_bias", C.c_longlong), ("out_dim", C.c_int), ("in_dim", C.c_int), ("ld", C.c_int), ("ks", C.c_int)]
+
+
+class PackActorArgs32(C.Structure):
+    _fields_ = [("src", vp), ("dst", vp), ("m", PackMat32 * 3)]
+
+
+class PendulumArgs(C.Structure):
+    _fields_ = [("theta", vp), ("theta_dot", vp), ("t", vp), ("ep_return", vp), ("action", vp), ("obs", vp),
+                ("next_obs", vp), ("reward", vp), ("done", vp), ("trunc", vp), ("noise", vp), ("stats", vp), ("counter", vp),
+                ("seed", C.c_ulonglong), ("E", C.c_int), ("ld_act", C.c_int), ("time_limit", C.c_int), ("init", C.c_int),
+                ("reward_scale", C.c_float), ("limit_terminal", C.c_int)]
+
+
+class RolloutRowsArgs(C.Structure):
+    _fields_ = [("obs", vp), ("act", vp), ("next_obs", vp), ("R", vp), ("gk", vp), ("nxt", vp), ("d", vp), ("rows", vp),
+                ("T", C.c_int), ("E", C.c_int), ("S", C.c_int), ("A", C.c_int), ("ld_act", C.c_int), ("row_ld", C.c_int)]
+
+
 class OuArgs(C.Structure):
     _fields_ = [("x", vp), ("action", vp), ("out", vp), ("sigma", vp), ("counter", vp), ("seed", C.c_ulonglong),
                 ("n", C.c_int), ("A", C.c_int), ("theta", C.c_float), ("mu", C.c_float), ("sigma_const", C.c_float),
@@ -276,7 +304,8 @@ class DevStateMirror(C.Structure):
                 ("pad_", C.c_longlong * 2)]
 
 
-_SIZE_CHECKED = (LayerW32, CriticPhaseArgs32, ActorPhaseArgs32, WgradGroup32)
+_SIZE_CHECKED = (LayerW32, CriticPhaseArgs32, ActorPhaseArgs32, WgradGroup32, ActorInferArgs32, PackActorArgs32,
+                 PendulumArgs, RolloutRowsArgs)
 
 # ---------------------------------------------------------------------------
 # loader
@@ -325,6 +354,15 @@ def lib() -> C.CDLL:
             ("d4pg_actor_phase32", [C.POINTER(ActorPhaseArgs32), C.c_int, vp]),
             ("d4pg_phase32_lds_bytes", [C.POINTER(PhaseDims), C.c_int, C.c_int]),
             ("d4pg_wgrad32", [C.POINTER(WgradGroup32), vp]),
+            ("d4pg_actor_infer32", [C.POINTER(ActorInferArgs32), C.c_int, vp]),
+            ("d4pg_pack_actor32", [C.POINTER(PackActorArgs32), vp]),
+            ("d4pg_pendulum_step", [C.POINTER(PendulumArgs), vp]),
+            ("d4pg_rollout_rows", [C.POINTER(RolloutRowsArgs), vp]),
+            ("d4pg_ipc_alloc", [C.c_size_t, C.POINTER(vp), C.c_char_p]),
+            ("d4pg_ipc_open", [C.c_char_p, C.POINTER(vp)]),
+            ("d4pg_ipc_close", [vp]),
+            ("d4pg_ipc_free", [vp]),
+            ("d4pg_memcpy_d2d_async", [vp, vp, C.c_size_t, vp]),
         ):
             fn = getattr(_lib, name)
             fn.argtypes = argt

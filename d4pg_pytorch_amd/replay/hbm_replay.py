@@ -122,7 +122,8 @@ class HbmReplay:
         n_total = staged.shape[0]
         off = 0
         while off < n_total:
-            n = min(self.chunk_max, n_total - off, self.capacity)
+            # uniform replay: one launch for the whole block; prioritised: chunks the tree update's staging holds
+            n = min(n_total - off, self.capacity, self.chunk_max if self.prioritized else n_total)
             part = staged[off: off + n]
             a = H.InsertArgs()
             a.rp = self._replay_desc()

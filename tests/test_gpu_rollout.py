@@ -1,0 +1,177 @@
+"""Device-resident acting (GPU only): the single-launch policy kernel, the on-device pendulum, and a
+rollout segment that turns into replay rows without a host hop, against their host implementations."""
+import numpy as np
+import pytest
+import torch
+
+from d4pg_pytorch_amd.config import default_config
+
+pytestmark = pytest.mark.gpu
+
+
+def _policy(S, A, Hd, seed=1):
+    from d4pg_pytorch_amd.models.nets import ActorPolicy, init_net_
+    pol = ActorPolicy(S, A, Hd)
+    init_net_(pol.view, 0.3, torch.Generator().manual_seed(seed))
+    return pol
+
+
+def _torch_policy(pol, x):
+    sd = pol.view.state_dict()
+    h = torch.relu(x @ sd["linear1.weight"].T + sd["linear1.bias"])
+    h = torch.relu(h @ sd["linear2.weight"].T + sd["linear2.bias"])
+    return torch.tanh(h @ sd["linear3.weight"].T + sd["linear3.bias"])
+
+
+@pytest.mark.parametrize("S,A,Hd,E", [(24, 4, 400, 48), (3, 1, 400, 1), (8, 2, 128, 37), (17, 6, 256, 1500),
+                                      (111, 8, 400, 4100), (24, 4, 72, 9)])
+def test_gpu_actor_single_launch_matches_fp32_reference(S, A, Hd, E):
+    from d4pg_pytorch_amd.actors.gpu_actor import GpuActor
+    pol = _policy(S, A, Hd)
+    gpu = GpuActor(S, A, Hd, max_batch=E, action_scale=1.5)
+    gpu.load_flat(pol.flat.numpy())
+    assert gpu.launches_per_act == (3 if Hd == 72 else 1)
+    x = torch.randn(E, S, generator=torch.Generator().manual_seed(2))
+    want = 1.5 * _torch_policy(pol, x.double().float())
+    got = gpu.act(x.numpy())
+    np.testing.assert_allclose(got, want.numpy(), rtol=1e-4, atol=2e-6)
+    k = max(1, E // 3)
+    np.testing.assert_allclose(gpu.act(x[:k].numpy()), want[:k].numpy(), rtol=1e-4, atol=2e-6)
+
+
+def test_pack_kernel_equals_host_packing():
+    from d4pg_pytorch_amd.actors.gpu_actor import PackedActor32
+    from d4pg_pytorch_amd.models.nets import pack32
+    pol = _policy(24, 4, 400)
+    pa = PackedActor32(24, 4, 400, "cuda")
+    flat = pol.flat.cuda()
+    pa.pack_from(flat.data_ptr())
+    torch.cuda.synchronize()
+    for s, p, boff in zip(pa.layout.layers, pa.packed, pa.bias_off):
+        w = flat[s.w_off: s.w_off + s.w_numel].view(s.out_dim, s.ld)[:, : s.in_dim]
+        assert torch.equal(pa.buf[p.off: p.off + p.numel], pack32(w, p))
+        assert torch.equal(pa.buf[boff: boff + s.out_dim], flat[s.b_off: s.b_off + s.out_dim])
+
+
+def test_device_pendulum_follows_the_host_pendulum():
+    from d4pg_pytorch_amd.envs.device_pendulum import DevicePendulum
+    from d4pg_pytorch_amd.envs.pendulum import PendulumVec
+    E, steps = 64, 230           # past the 200-step limit: resets happen on both sides
+    dev = DevicePendulum(E, "cuda", seed=3)
+    obs = torch.zeros(E, 3, device="cuda")
+    dev.reset(obs)
+    torch.cuda.synchronize()
+    host = PendulumVec(E, seed=0)
+    host.reset()
+    host.theta[:] = dev.theta.cpu().double().numpy()
+    host.theta_dot[:] = dev.theta_dot.cpu().double().numpy()
+    assert np.all(np.abs(host.theta) <= np.pi) and np.all(np.abs(host.theta_dot) <= 1)
+    nobs, rew, done, trunc = (torch.zeros(E, 3, device="cuda"), torch.zeros(E, device="cuda"),
+                              torch.zeros(E, device="cuda"), torch.zeros(E, device="cuda"))
+    g = torch.Generator().manual_seed(4)
+    ret = np.zeros(E)
+    for t in range(steps):
+        act = (torch.rand(E, 4, generator=g) * 5 - 2.5).cuda()
+        dev.step(act, obs, nobs, rew, done, trunc)
+        torch.cuda.synchronize()
+        o_h, r_h, d_h = host._step(act[:, :1].cpu().numpy())
+        ret += r_h
+        np.testing.assert_allclose(nobs.cpu().numpy(), o_h, rtol=0, atol=2e-3 if t > 50 else 2e-4)
+        np.testing.assert_allclose(rew.cpu().numpy() * 100.0, r_h, rtol=1e-3, atol=2e-3)
+        assert np.array_equal(done.cpu().numpy() > 0.5, d_h) and not trunc.any()
+        if d_h.any():
+            assert t == 199 and d_h.all()
+            mean_ret, n = dev.episode_stats()
+            assert n == E and abs(mean_ret - ret.mean()) < 0.5
+            assert (dev.t == 0).all()
+            host.theta[:] = dev.theta.cpu().double().numpy()          # fresh episode drawn on the device
+            host.theta_dot[:] = dev.theta_dot.cpu().double().numpy()
+            host.t[:] = 0
+            assert np.all(np.abs(host.theta) <= np.pi) and np.all(np.abs(host.theta_dot) <= 1)
+            np.testing.assert_allclose(obs.cpu().numpy(), host._obs(), atol=1e-5)
+        else:
+            assert torch.equal(obs, nobs)
+            host.theta[:] = dev.theta.cpu().double().numpy()          # re-anchor: fp32 vs fp64 integration drifts
+            host.theta_dot[:] = dev.theta_dot.cpu().double().numpy()
+
+
+def _rollout(explore, use_graph, n=5, T=16, E=96, seed=5, prioritized=0):
+    from d4pg_pytorch_amd.actors.gpu_rollout import DeviceRollout
+    from d4pg_pytorch_amd.envs.device_pendulum import DevicePendulum
+    from d4pg_pytorch_amd.models.core import build_core
+    from d4pg_pytorch_amd.replay.hbm_replay import HbmReplay
+    cfg = default_config(env="Pendulum-v0", model="d4pg", batch_size=64, dense_size=128, device="cuda",
+                         n_step_returns=n, replay_mem_size=20_000, v_min=-20.0, v_max=0.0,
+                         replay_memory_prioritized=prioritized, random_seed=seed)
+    core = build_core(cfg, "cuda")
+    rp = HbmReplay(cfg, "cuda", core.dev_state)
+    env = DevicePendulum(E, "cuda", seed=seed, time_limit=20)       # several episode ends inside a segment
+    ro = DeviceRollout(cfg, env, rp, "cuda", segment=T, seed=seed, explore=explore, use_graph=use_graph)
+    ro.refresh_weights(core.online.flat.data_ptr(), core.layout.actor.base)
+    return cfg, core, rp, ro
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_rollout_rows_equal_the_host_nstep_assembler(use_graph):
+    from d4pg_pytorch_amd.actors.native import NStepAssembler
+    cfg, core, rp, ro = _rollout(explore=True, use_graph=use_graph)
+    T, E, S, A, n = ro.T, ro.E, ro.S, ro.A, ro.n
+    ends = 0
+    for seg in range(3):
+        assert ro.collect() == T * E
+        torch.cuda.synchronize()
+        obs, act, nobs = ro.obs[:T].cpu().numpy(), ro.act.cpu().numpy()[:, :, :A], ro.next_obs.cpu().numpy()
+        rew, done, trunc = ro.reward.cpu().numpy(), ro.done.cpu().numpy() > 0.5, ro.trunc.cpu().numpy() > 0.5
+        ends += int(done.sum())
+        assert np.abs(act).max() <= 2.0 and not trunc.any()
+        # the policy saw what the environment produced: obs[t+1] is next_obs[t] unless an episode ended there
+        cont = ~done[:-1]
+        np.testing.assert_array_equal(obs[1:][cont], nobs[:-1][cont])
+        got = ro.rows.cpu().numpy().reshape(T, E, -1)
+        for e in range(E):
+            asm = NStepAssembler(1, n, S, A, cfg["discount_rate"])
+            out = []
+            for t in range(T):
+                # a segment boundary closes the window like a truncation
+                out.extend(asm.push(obs[t, e], act[t, e], rew[t, e], nobs[t, e], done[t, e: e + 1],
+                                    np.array([t == T - 1])))
+            assert len(out) == T
+            want = np.stack(out)                   # emitted oldest first = time order
+            np.testing.assert_allclose(got[:, e, : 2 * S + A + 3], want[:, : 2 * S + A + 3], rtol=1e-6, atol=1e-7)
+    assert ends == 2 * E                           # 48 steps of 20-step episodes
+    assert rp.size == 3 * T * E and core.read_dev_state().replay_size == 3 * T * E
+    # rows in the replay are those rows
+    assert torch.equal(rp.rows[2 * T * E: 3 * T * E], ro.rows)
+
+
+def test_rollout_without_noise_plays_the_policy_and_graph_equals_eager():
+    _, core, _, ro_g = _rollout(explore=False, use_graph=True)
+    _, _, _, ro_e = _rollout(explore=False, use_graph=False)
+    for _ in range(2):
+        ro_g.collect()
+        ro_e.collect()
+    torch.cuda.synchronize()
+    assert torch.equal(ro_g.rows, ro_e.rows)
+    from d4pg_pytorch_amd.actors.gpu_actor import GpuActor
+    ga = GpuActor(ro_g.S, ro_g.A, int(core.cfg["dense_size"]), max_batch=ro_g.E)
+    n_act = ga.layout.numel
+    ga.load_flat(core.online.flat.detach()[core.layout.actor.base: core.layout.actor.base + n_act].cpu().numpy())
+    want = ga.act(ro_g.obs[3].cpu().numpy())
+    np.testing.assert_allclose(ro_g.act[3].cpu().numpy()[:, : ro_g.A], want, rtol=1e-5, atol=1e-6)
+
+
+def test_learner_trains_from_device_rollouts():
+    cfg, core, rp, ro = _rollout(explore=True, use_graph=True, T=32, E=256)
+    core.attach_replay(rp)
+    for it in range(6):
+        ro.refresh_weights(core.online.flat.data_ptr(), core.layout.actor.base)
+        ro.collect()
+        done = 0
+        while done < 32:
+            done += core.update_from_replay_many(32 - done)
+    torch.cuda.synchronize()
+    assert core.read_dev_state().step_done == 6 * 32
+    m = core.read_metrics()
+    assert np.isfinite(m["value_loss"]) and np.isfinite(m["policy_loss"])
+    mean_ret, n_ep = ro.episode_stats()
+    assert n_ep > 0 and -400 < mean_ret < 0      # 20-step episodes
