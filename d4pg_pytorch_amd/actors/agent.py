@@ -44,7 +44,7 @@ def make_policy(config: Dict, device: str):
 class Agent:
     def __init__(self, config: Dict, policy, ctrl: ControlBlock, n_agent: int = 0,
                  agent_type: str = "exploration", log_dir: str = "", ring: Optional[ShmRing] = None,
-                 slab: Optional[WeightSlab] = None, seed: Optional[int] = None):
+                 slab: Optional[WeightSlab] = None, seed: Optional[int] = None, hb_slot: Optional[int] = None):
         self.config = config
         self.n_agent = n_agent
         self.agent_type = agent_type
@@ -72,10 +72,49 @@ class Agent:
         self.episode_rewards = []
         self.env_steps = 0
         self.weight_versions_seen = 0
+        self.hb_slot = n_agent + 1 if hb_slot is None else int(hb_slot)
+        self._gpu_version = 0
+        self.shared_weights = False         # True once the policy follows the learner's device buffer (HIP IPC)
 
     # ------------------------------------------------------------------ weights
+    def _try_attach_shared(self) -> None:
+        """GPU agent on the learner's device: map the learner's weight buffer (``parallel/hip_ipc.py``)."""
+        self._attach_tried = True
+        if not (hasattr(self.actor, "attach_shared") and self.config.get("share_weights_ipc", True)):
+            return
+        try:
+            from ..parallel.hip_ipc import SharedDeviceBuffer, read_handle
+            got = read_handle(self.ctrl.name)
+            if got is None:
+                self._attach_tried = False           # the learner has not exported yet: look again next time
+                return
+            handle, numel, dev_index = got
+            if (self.actor.device.index or 0) != dev_index:
+                return
+            self.actor.attach_shared(SharedDeviceBuffer.open(handle, numel, self.actor.device), self._half)
+            self.shared_weights = True
+            if self.logger is not None:
+                self.logger.scalar_summary("agent/shared_device_weights", 1.0, 0)
+        except Exception as exc:      # pragma: no cover - depends on the host's IPC support
+            print(f"[agent {self.n_agent}] device weight sharing unavailable ({exc}); using the host slab", flush=True)
+
     def update_actor_learner(self) -> bool:
         """Pull the newest published weights (``models/agent.py:37-49``)."""
+        if not getattr(self, "_attach_tried", False):
+            self._try_attach_shared()
+        if self.shared_weights:
+            v = self.ctrl.load(ControlBlock.GPU_WEIGHT_VERSION)
+            if v == self._gpu_version:
+                return False
+            while True:                   # a slot is rewritten two publications later: repack if that overtook us
+                self.actor.refresh_shared(v)
+                v2 = self.ctrl.load(ControlBlock.GPU_WEIGHT_VERSION)
+                if v2 < v + 2:
+                    break
+                v = v2
+            self._gpu_version = v
+            self.weight_versions_seen += 1
+            return True
         if self.reader is None:
             return False
         if not self.reader.poll():
@@ -127,7 +166,7 @@ class Agent:
                 print_mark = self.env_steps // 5000 + 1
                 print(f"[agent {self.n_agent}] reward {self.episode_rewards[-1]:.2f} env_steps {self.env_steps} "
                       f"time {int(time.time() - t_start)}s", flush=True)
-            ctrl.heartbeat(self.n_agent + 1, int(time.time() * 1000))
+            ctrl.heartbeat(self.hb_slot, int(time.time() * 1000))
         if self.ring is not None:
             self.ring.mark_closed()
         if self.logger is not None:

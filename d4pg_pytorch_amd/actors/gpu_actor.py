@@ -116,7 +116,7 @@ class GpuActor:
             self.h2 = torch.zeros(self.E, ldh, device=self.device)
         self.launches_per_act = 1 if self.fused is not None else 3
         self._shared = None
-        self._shared_base = 0
+        self._shared_half = 0
 
     # ------------------------------------------------------------------ weights
     def load_flat(self, flat) -> None:
@@ -126,18 +126,23 @@ class GpuActor:
             self.fused.pack_from(self.flat.data_ptr())
 
     def attach_shared(self, shared, actor_index: int) -> None:
-        """Follow the learner's weights in place: ``shared`` is a ``SharedDeviceBuffer`` holding
-        ``[online actor | target actor]``; ``actor_index`` 0 / 1 selects which."""
-        self._shared, self._shared_base = shared, actor_index * self.layout.numel
-        self.refresh_shared()
+        """Follow the learner's weights in place.  ``shared`` is the learner's ``SharedDeviceBuffer``: two
+        slots of ``[online actor | target actor]`` written alternately (``models/learner.py::WeightPublisher``);
+        ``actor_index`` 0 / 1 selects the online / target half."""
+        assert shared.numel == 4 * self.layout.numel
+        self._shared, self._shared_half = shared, int(actor_index)
 
-    def refresh_shared(self) -> bool:
-        if self._shared is None:
+    def refresh_shared(self, version: int) -> bool:
+        """Repack the policy from the slot that holds publication ``version`` (1-based count of completed
+        publications).  Returns False without a shared buffer or before the first publication."""
+        if self._shared is None or version < 1:
             return False
         n = self.layout.numel
-        self.flat.copy_(self._shared.tensor[self._shared_base: self._shared_base + n], non_blocking=True)   # for state_dict()
+        base = ((version - 1) % 2) * 2 * n + self._shared_half * n
+        self.flat.copy_(self._shared.tensor[base: base + n], non_blocking=True)      # for state_dict() / checkpoints
         if self.fused is not None:
-            self.fused.pack_from(self._shared.ptr, self._shared_base)      # straight out of the learner's memory
+            self.fused.pack_from(self._shared.ptr, base)      # straight out of the learner's memory
+        torch.cuda.current_stream(self.device).synchronize()
         return True
 
     def _slot(self, i):

@@ -61,14 +61,15 @@ class DeviceRollout:
         self.use_graph = bool(use_graph)
         self._graph = None
         self.env_steps = 0
+        self._in_flight = self._started = False
         with torch.cuda.stream(self.stream):
             self.env.reset(self.obs[0])
         self.stream.synchronize()
 
     # ------------------------------------------------------------------ weights
     def refresh_weights(self, flat_ptr: int, actor_base: int = 0) -> None:
-        """Repack the policy from flat fp32 parameters on this device (the learner's own buffer or an IPC
-        mapping).  Ordered after the caller's stream, ahead of the next segment."""
+        """Repack the policy from flat fp32 parameters on this device.  Ordered after the caller's stream,
+        ahead of the next segment."""
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
         self.stream.wait_event(ev)
@@ -125,19 +126,21 @@ class DeviceRollout:
             if was:
                 gc.enable()
 
-    def collect(self, insert: bool = True) -> int:
-        """One segment: ``T * E`` environment steps and as many replay rows.  The segment runs on the
-        rollout's stream; the insert is enqueued on the caller's stream behind it.  Returns the steps."""
+    def launch(self, flat_ptr: Optional[int] = None, actor_base: int = 0) -> None:
+        """Enqueue one segment on the rollout's stream, ordered behind what the caller's stream holds now (the
+        insert of the previous segment's rows, a consistent set of weights).  With ``flat_ptr`` the policy is
+        first repacked from those flat fp32 parameters (the learner's own buffer or an IPC mapping)."""
+        assert not self._in_flight, "drain() the previous segment first"
         main = torch.cuda.current_stream(self.device)
-        if self.env_steps == 0:
-            self.obs[self.T].copy_(self.obs[0])
-            ev = torch.cuda.Event()
-            ev.record(main)
-            self.stream.wait_event(ev)
-        # the previous segment's rows must have been consumed by their insert (main stream) before they are overwritten
-        ev_main = torch.cuda.Event()
-        ev_main.record(main)
-        self.stream.wait_event(ev_main)
+        if not self._started:
+            self.obs[self.T].copy_(self.obs[0])     # a segment starts from obs[T] of the one before
+            self._started = True
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self.stream.wait_event(ev)
+        if flat_ptr is not None:
+            with torch.cuda.stream(self.stream):
+                self.actor.pack_from(flat_ptr, actor_base)
         if self.use_graph and self._graph is None:
             self._capture()                        # makes the first segment itself
         elif self.use_graph:
@@ -147,11 +150,32 @@ class DeviceRollout:
             with torch.cuda.stream(self.stream):
                 self._enqueue_segment()
         self.done_event.record(self.stream)
-        main.wait_event(self.done_event)
+        self._in_flight = True
+
+    def drain(self, insert: bool = True) -> int:
+        """The caller's stream waits (on the device) for the segment in flight and inserts its rows into the
+        replay.  Returns the environment steps they hold."""
+        if not self._in_flight:
+            return 0
+        torch.cuda.current_stream(self.device).wait_event(self.done_event)
         if insert:
             self.replay.insert(self.rows)
+        self._in_flight = False
         self.env_steps += self.T * self.E
         return self.T * self.E
+
+    def collect(self, insert: bool = True) -> int:
+        """One segment start to finish: ``T * E`` environment steps and as many replay rows."""
+        self.launch()
+        return self.drain(insert)
+
+    def collect_overlapped(self, flat_ptr: Optional[int] = None, actor_base: int = 0) -> int:
+        """Insert the rows of the segment launched by the previous call and launch the next one, which then
+        runs on its own stream beside whatever the caller enqueues next (the learner's updates leave most of
+        the 256 CUs idle).  Returns the environment steps inserted by this call."""
+        n = self.drain()
+        self.launch(flat_ptr, actor_base)
+        return n
 
     def episode_stats(self) -> Tuple[Optional[float], int]:
         return self.env.episode_stats()

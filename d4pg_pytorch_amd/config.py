@@ -89,6 +89,11 @@ EXTENSION_DEFAULTS: Dict[str, Any] = {
                                      # | "auto": replicated up to a global batch of 8192 rows, else grad_allreduce
     "exploiter_device": None,        # default: same as ``device``
     "envs_per_agent": 1,             # vectorised environments per explorer/exploiter process
+    "gpu_rollout_envs": 0,           # > 0: that many explorer environments stepped ON the learner's GPU (policy, noise,
+                                     # dynamics, n-step rows and replay insert without a host hop; envs/device_pendulum.py)
+    "gpu_rollout_segment": 32,       # environment steps per captured rollout segment
+    "gpu_rollout_interval": 32,      # learner updates between two segments
+    "share_weights_ipc": True,       # GPU agents read the learner's weights in place through HIP IPC
     "replay_device": "auto",         # "hbm" (inside the learner, on its GPU) | "host" (sampler process) | "auto"
     "weight_publish_interval": 100,  # learner updates between actor-weight publications (d4pg.py:141)
     "lossless_replay_queue": True,   # back-pressure instead of silently dropping transitions
@@ -150,7 +155,7 @@ _INT_KEYS = {
     "batch_queue_size", "replay_memory_prioritized", "num_episode_save", "save_buffer_on_disk",
     "dense_size", "num_atoms", "num_learners", "envs_per_agent", "weight_publish_interval",
     "max_env_steps_per_agent", "metrics_interval", "ring_capacity", "ingest_chunk", "ingest_interval", "sample_ahead", "control_interval",
-    "ou_decay_period", "learner_checkpoint_interval",
+    "ou_decay_period", "learner_checkpoint_interval", "gpu_rollout_envs", "gpu_rollout_segment", "gpu_rollout_interval",
 }
 _FLOAT_KEYS = {
     "action_low", "action_high", "priority_alpha", "priority_beta_start", "priority_beta_end",
@@ -161,7 +166,7 @@ _FLOAT_KEYS = {
 }
 _BOOL_KEYS = {
     "use_per_sample_gamma", "scale_action", "lossless_replay_queue", "use_hip_graph",
-    "synthetic_env", "check_rings",
+    "synthetic_env", "check_rings", "share_weights_ipc",
 }
 
 
@@ -266,6 +271,9 @@ def finalize_config(raw: Dict[str, Any]) -> Dict[str, Any]:
     need(cfg["dp_mode"] in ("auto", "replicated", "grad_allreduce"),
          "dp_mode must be 'auto', 'replicated' or 'grad_allreduce'")
     need(cfg["envs_per_agent"] >= 1, "envs_per_agent must be >= 1")
+    need(cfg["gpu_rollout_envs"] >= 0 and cfg["gpu_rollout_segment"] >= 1 and cfg["gpu_rollout_interval"] >= 1,
+         "gpu_rollout_envs must be >= 0, gpu_rollout_segment and gpu_rollout_interval >= 1")
+    need(cfg["gpu_rollout_envs"] == 0 or str(cfg["device"]).startswith("cuda"), "gpu_rollout_envs needs device: cuda")
     need(cfg["critic_loss"] in ("bce", "ce"), "critic_loss must be 'bce' or 'ce'")
     need(cfg["compute_dtype"] in ("auto", "fp32", "bf16"), "compute_dtype must be 'auto', 'fp32' or 'bf16'")
     need(cfg["replay_device"] in ("auto", "hbm", "host"), "replay_device must be auto|hbm|host")
@@ -277,7 +285,9 @@ def finalize_config(raw: Dict[str, Any]) -> Dict[str, Any]:
     # A job needs at least one explorer to produce data: the reference ships
     # ``walker2d_d4pg.yml`` with num_agents: 1, which can never train
     # (only explorers write to the replay queue, models/agent.py:101-105).
-    if cfg["num_agents"] < 2:
+    if cfg["num_agents"] < 2 and cfg["gpu_rollout_envs"] > 0:
+        cfg["num_agents"] = max(1, cfg["num_agents"])        # the device explorers produce the data
+    elif cfg["num_agents"] < 2:
         warnings.warn("num_agents < 2 leaves no explorer to generate data; using 2", stacklevel=2)
         cfg["num_agents"] = 2
 

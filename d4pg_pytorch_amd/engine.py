@@ -86,7 +86,7 @@ def learner_worker(config: Dict, ctrl_name: str, slab_name: str, ring_names: Lis
 
 
 def sampler_worker(config: Dict, ctrl_name: str, ring_names: List[str], batch_queue, priority_queue,
-                   log_dir: str) -> None:
+                   log_dir: str, hb_slot: Optional[int] = None) -> None:
     """Replay owner of the host topology (``models/d4pg/engine.py:23-77``)."""
     from .replay.host_replay import HostReplay
     _set_threads(1)
@@ -126,7 +126,7 @@ def sampler_worker(config: Dict, ctrl_name: str, ring_names: List[str], batch_qu
                 logger.scalar_summary("data_struct/replay_queue", sum(len(r) for r in rings), step)
                 logger.scalar_summary("data_struct/batch_queue", batch_queue.qsize() if hasattr(batch_queue, "qsize") else 0, step)
                 logger.scalar_summary("data_struct/replay_buffer", len(replay), step)
-            ctrl.heartbeat(ctrl.n_workers - 1, int(now * 1000))
+            ctrl.heartbeat(ctrl.n_workers - 1 if hb_slot is None else hb_slot, int(now * 1000))
         if config.get("save_buffer_on_disk"):
             replay.dump(os.path.join(config["results_path"], "replay_buffer.pkl"))
         logger.close()
@@ -143,7 +143,7 @@ def sampler_worker(config: Dict, ctrl_name: str, ring_names: List[str], batch_qu
 
 
 def agent_worker(config: Dict, ctrl_name: str, slab_name: str, ring_name: Optional[str], n_agent: int,
-                 agent_type: str, log_dir: str) -> None:
+                 agent_type: str, log_dir: str, hb_slot: Optional[int] = None) -> None:
     """Explorer / exploiter process (``models/d4pg/engine.py:86-94``)."""
     from .actors.agent import Agent, make_policy
     _set_threads(1)
@@ -157,7 +157,7 @@ def agent_worker(config: Dict, ctrl_name: str, slab_name: str, ring_name: Option
             device = "cpu"
     policy = make_policy(config, device)
     agent = Agent(config, policy, ctrl, n_agent=n_agent, agent_type=agent_type, log_dir=log_dir,
-                  ring=ring, slab=slab)
+                  ring=ring, slab=slab, hb_slot=hb_slot)
     agent.run()
 
 
@@ -171,6 +171,8 @@ class Engine:
         self.final_env_steps = 0
         self.final_episodes = 0
         self.restarts = 0
+        self.hung_killed = 0
+        self.hb_slots: Dict[str, int] = {}
 
     def _spawn(self, ctx, name: str, target, args) -> mp.Process:
         p = ctx.Process(target=target, args=args, name=name, daemon=False)
@@ -195,13 +197,17 @@ class Engine:
         from .models.nets import NetLayout
         from .replay.hbm_replay import row_ld
         n_actor = NetLayout.build(cfg["state_dim"], cfg["dense_size"], cfg["action_dim"]).numel
-        ctrl = ControlBlock.create(n_workers=total_agents + 4)
+        ctrl = ControlBlock.create(n_workers=world + total_agents + 2)
         slab = WeightSlab.create(2 * n_actor)
         rings: List[ShmRing] = []
         names = [ctrl.name, slab.name]
         procs: Dict[str, mp.Process] = {}
         specs: Dict[str, tuple] = {}
         batch_queue = priority_queue = None
+        # one heartbeat slot per process: learner ranks first, then the agents, the sampler last
+        self.hb_slots = {f"learner-{r}": r for r in range(world)}
+        self.hb_slots.update({f"agent-{i}": world + i for i in range(total_agents)})
+        self.hb_slots["sampler"] = world + total_agents
         try:
             rl = row_ld(cfg["state_dim"], cfg["action_dim"])
             for _ in range(world * n_explorers_per_rank):
@@ -216,15 +222,17 @@ class Engine:
                 batch_queue = ctx.Queue(maxsize=int(cfg["batch_queue_size"]))
                 priority_queue = ctx.Queue(maxsize=int(cfg["replay_queue_size"])) \
                     if cfg["replay_memory_prioritized"] else None
-                specs["sampler"] = (sampler_worker, (cfg, ctrl.name, ring_names, batch_queue, priority_queue, exp_dir))
+                specs["sampler"] = (sampler_worker, (cfg, ctrl.name, ring_names, batch_queue, priority_queue, exp_dir,
+                                                     self.hb_slots["sampler"]))
             for rank in range(world):
                 mine = ring_names[rank * n_explorers_per_rank:(rank + 1) * n_explorers_per_rank]
                 specs[f"learner-{rank}"] = (learner_worker, (cfg, ctrl.name, slab.name, mine, exp_dir, rank, world,
                                                              port, batch_queue, priority_queue))
-            specs["agent-0"] = (agent_worker, (cfg, ctrl.name, slab.name, None, 0, "exploitation", exp_dir))
+            specs["agent-0"] = (agent_worker, (cfg, ctrl.name, slab.name, None, 0, "exploitation", exp_dir,
+                                               self.hb_slots["agent-0"]))
             for i in range(world * n_explorers_per_rank):
                 specs[f"agent-{i + 1}"] = (agent_worker, (cfg, ctrl.name, slab.name, ring_names[i], i + 1,
-                                                          "exploration", exp_dir))
+                                                          "exploration", exp_dir, self.hb_slots[f"agent-{i + 1}"]))
             # learners first: agents block on nothing, but fresh weights should exist early
             for name, (fn, args) in specs.items():
                 procs[name] = self._spawn(ctx, name, fn, args)
@@ -258,6 +266,10 @@ class Engine:
             for r in rings:
                 r.close()
             slab.close()
+            try:
+                os.unlink(os.path.join("/dev/shm", ctrl.name.strip("/") + ".hipipc"))    # device weight handle
+            except OSError:
+                pass
             ctrl.close()
             cleanup_names(names)
         if failed:
@@ -294,10 +306,33 @@ class Engine:
                         ctrl.store(ControlBlock.FAILED, 1)
                         ctrl.request_stop()
                         return
-            if ctrl.load(ControlBlock.LEARNER_ALIVE):
-                hb = ctrl.last_heartbeat(0)
-                if hb and time.time() * 1000.0 - hb > hb_timeout_ms:
-                    print("[engine] learner heartbeat lost: stopping the job", flush=True)
+            # heartbeats: a process that has beaten once and then falls silent is hung (blocked in a collective, a
+            # dead GPU queue, an environment that never returns).  Hung explorers are replaced like crashed ones;
+            # a hung learner rank or sampler ends the job (its peers sit in the same collectives).
+            now_ms = time.time() * 1000.0
+            for name, p in list(procs.items()):
+                slot = self.hb_slots.get(name)
+                if slot is None or not p.is_alive():
+                    continue
+                hb = ctrl.last_heartbeat(slot)
+                if not hb or now_ms - hb <= hb_timeout_ms:
+                    continue
+                if name.startswith("learner") or name == "sampler":
+                    print(f"[engine] {name} heartbeat lost: stopping the job", flush=True)
+                    ctrl.store(ControlBlock.FAILED, 1)
+                    ctrl.request_stop()
+                    return
+                print(f"[engine] {name} heartbeat lost: killing it", flush=True)
+                p.kill()
+                p.join(timeout=5.0)
+                ctrl.heartbeat(slot, 0)
+                self.hung_killed += 1
+                if self.restarts < max_restarts:
+                    self.restarts += 1
+                    fn, args = specs[name]
+                    procs[name] = self._spawn(ctx, name, fn, args)
+                else:
+                    print(f"[engine] {name} keeps hanging: stopping the job", flush=True)
                     ctrl.store(ControlBlock.FAILED, 1)
                     ctrl.request_stop()
                     return

@@ -28,6 +28,7 @@ class DevicePendulum:
         self.stats = z(2, dt=torch.float64)
         self.counter = z(1, dt=torch.int64)
         self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self._seen = (0.0, 0)
         self.limit_terminal = bool(limit_terminal)      # like PendulumVec: the 200-step limit reads as done
         self.noise: Optional[torch.Tensor] = None       # [E, ld_act] exploration-noise state to zero at episode ends
 
@@ -60,13 +61,14 @@ class DevicePendulum:
         a.reward, a.done, a.trunc = reward_out.data_ptr(), done_out.data_ptr(), trunc_out.data_ptr()
         H.launch("d4pg_pendulum_step", a)
 
-    def episode_stats(self, reset: bool = True) -> Tuple[Optional[float], int]:
-        """(mean unscaled return, count) of the episodes finished since the last call; synchronises."""
+    def episode_stats(self) -> Tuple[Optional[float], int]:
+        """(mean unscaled return, count) of the episodes finished since the last call; synchronises.  The device
+        totals only ever grow (a rollout may be stepping on another stream), the difference is taken here."""
         s = self.stats.cpu()
-        n = int(s[1].item())
-        if reset:
-            self.stats.zero_()
-        return (float(s[0].item()) / n if n else None), n
+        total, count = float(s[0].item()), int(s[1].item())
+        d_total, d_count = total - self._seen[0], count - self._seen[1]
+        self._seen = (total, count)
+        return (d_total / d_count if d_count else None), d_count
 
 
 def make_device_env(cfg, num_envs: int, device, seed: int = 0):

@@ -79,6 +79,97 @@ class RingIngestor:
         return n
 
 
+class WeightPublisher:
+    """Publication of ``[online actor | target actor]`` that never makes the learner wait for the GPU.
+
+    The reference pushes a CPU copy of the weights into a queue every 100 updates, which synchronises the
+    device each time (``models/d4pg/d4pg.py:141-146``).  Here a publication is three enqueues:
+
+    1. on the update stream, two device-to-device copies take a consistent snapshot into one of two staging
+       slots (the slots are a HIP-IPC buffer when GPU agents follow the learner in place,
+       ``parallel/hip_ipc.py``);
+    2. a side stream, ordered behind that snapshot by an event, copies the slot into pinned host memory;
+    3. :meth:`poll` (called from the learner's loop) sees the copy's event complete and only then writes the
+       seq-locked slab for CPU agents and raises the version GPU agents watch.
+
+    A slot is rewritten two publications later; the update stream waits (on the device) for the event of the
+    copy that last read it, which has long completed by then."""
+
+    def __init__(self, core, slab: Optional[WeightSlab], ctrl: ControlBlock, device, shared=None):
+        self.core, self.slab, self.ctrl, self.device = core, slab, ctrl, torch.device(device)
+        self.n = core.layout.actor.numel
+        self.cuda = self.device.type == "cuda"
+        self.shared = shared
+        self.issued = self.completed = 0
+        if self.cuda:
+            if shared is not None:
+                assert shared.numel == 4 * self.n
+                self.stage = shared.tensor.view(2, 2 * self.n)
+            else:
+                self.stage = torch.zeros(2, 2 * self.n, device=self.device)
+            self.pinned = [torch.zeros(2 * self.n).pin_memory() for _ in range(2)]
+            self.side = torch.cuda.Stream(device=self.device)
+            self.pending = [None, None]            # per slot: (event of the D2H copy, learner step)
+            self.read_done = [None, None]          # per slot: event after which the slot may be rewritten
+        else:
+            self.host = torch.zeros(2 * self.n)
+
+    def publish(self) -> None:
+        n, core = self.n, self.core
+        step = int(core.step)
+        if not self.cuda:
+            with torch.no_grad():
+                self.host[:n].copy_(core.online.actor_flat().detach())
+                self.host[n:].copy_(core.target.actor_flat().detach())
+            if self.slab is not None:
+                self.slab.publish(self.host.numpy(), step)
+            return
+        slot = self.issued % 2
+        if self.pending[slot] is not None:         # two publications in flight: finish the older one first
+            self._complete(slot, block=True)
+        main = torch.cuda.current_stream(self.device)
+        if self.read_done[slot] is not None:
+            main.wait_event(self.read_done[slot])
+        with torch.no_grad():
+            self.stage[slot, :n].copy_(core.online.actor_flat().detach(), non_blocking=True)
+            self.stage[slot, n:].copy_(core.target.actor_flat().detach(), non_blocking=True)
+        snap = torch.cuda.Event()
+        snap.record(main)
+        self.side.wait_event(snap)
+        with torch.cuda.stream(self.side):
+            self.pinned[slot].copy_(self.stage[slot], non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(self.side)
+        self.pending[slot] = (done, step)
+        self.read_done[slot] = done
+        self.issued += 1
+
+    def _complete(self, slot: int, block: bool) -> bool:
+        done, step = self.pending[slot]
+        if block:
+            done.synchronize()
+        elif not done.query():
+            return False
+        if self.slab is not None:
+            self.slab.publish(self.pinned[slot].numpy(), step)
+        self.pending[slot] = None
+        self.completed += 1
+        self.ctrl.store(ControlBlock.GPU_WEIGHT_STEP, step)
+        self.ctrl.store(ControlBlock.GPU_WEIGHT_VERSION, self.completed)     # newest snapshot: slot (version - 1) % 2
+        return True
+
+    def poll(self, block: bool = False) -> int:
+        """Hand finished snapshots to the agents, oldest first.  Returns how many completed."""
+        if not self.cuda:
+            return 0
+        n = 0
+        while self.completed < self.issued:
+            if not self._complete(self.completed % 2, block):
+                break
+            n += 1
+        return n
+
+
 class Learner:
     """Policy and value network update routine (process level)."""
 
@@ -107,27 +198,43 @@ class Learner:
         self.logger = Logger(os.path.join(log_dir, "learner"), config.get("log_backend", "tb")) \
             if (log_dir and rank == 0) else None
         self.timing_tag = "learner/learner_update_timing" if config["model"] == "d4pg" else "learner/update_time"
-        n_actor = self.core.layout.actor.numel
-        self._pub_host = torch.zeros(2 * n_actor)
-        if self.device.type == "cuda":
-            self._pub_host = self._pub_host.pin_memory()
-        self._n_actor = n_actor
+        self.hb_slot = rank                      # heartbeat slot of this learner rank (engine.py: learners come first)
+        self._shared = None
+        if (rank == 0 and self.device.type == "cuda" and config.get("share_weights_ipc", True)
+                and str(config.get("exploiter_device", "cpu")).startswith("cuda")):
+            self._shared = self._export_weights()
+        self.publisher = WeightPublisher(self.core, slab, ctrl, self.device, self._shared) if rank == 0 else None
+        self.rollout = None
         self._last_metrics_t = time.time()
         self._last_metrics_step = self.core.step
         self._last_env_steps = 0
 
     # ----------------------------------------------------------------- weights
-    def publish_weights(self) -> None:
-        """[online actor | target actor] -> seq-locked slab (all agents read it)."""
-        if self.slab is None or self.rank != 0:
+    def _export_weights(self):
+        """A HIP-IPC buffer of two ``[online actor | target actor]`` slots for GPU agents on this machine; its
+        handle is left next to the control block.  ``None`` when the runtime refuses (agents then use the slab)."""
+        try:
+            from ..parallel.hip_ipc import SharedDeviceBuffer, write_handle
+            shared = SharedDeviceBuffer.create(4 * self.core.layout.actor.numel, self.device)
+            write_handle(self.ctrl.name, shared.handle, shared.numel, self.device.index or 0)
+            return shared
+        except Exception as exc:      # pragma: no cover - depends on the host's IPC support
+            print(f"[learner] device weight sharing unavailable ({exc}); agents read the host slab", flush=True)
+            return None
+
+    def publish_weights(self, wait: bool = False) -> None:
+        """[online actor | target actor] -> every agent (seq-locked slab; HIP-IPC slots for GPU agents).
+        Enqueue only unless ``wait``: the hand-over completes in :meth:`WeightPublisher.poll`."""
+        if self.publisher is None:
             return
-        n = self._n_actor
-        with torch.no_grad():
-            self._pub_host[:n].copy_(self.core.online.actor_flat().detach(), non_blocking=True)
-            self._pub_host[n:].copy_(self.core.target.actor_flat().detach(), non_blocking=True)
-        if self.device.type == "cuda":
-            torch.cuda.current_stream(self.device).synchronize()
-        self.slab.publish(self._pub_host.numpy(), self.core.step)
+        self.publisher.publish()
+        if wait:
+            self.publisher.poll(block=True)
+
+    def _beat(self) -> None:
+        self.ctrl.heartbeat(self.hb_slot, int(time.time() * 1000))
+        if self.publisher is not None:
+            self.publisher.poll()
 
     # ----------------------------------------------------------------- logging
     def _log_metrics(self, extra: Optional[Dict[str, float]] = None) -> None:
@@ -169,7 +276,7 @@ class Learner:
             self.publish_weights()
         if crossed(int(cfg["metrics_interval"])):
             self._log_metrics(extra_fn() if extra_fn else None)
-            self.ctrl.heartbeat(0, int(time.time() * 1000))
+        self._beat()
         if crossed(1000) and self.rank == 0:
             print("Training step ", step - step % 1000, flush=True)
         if crossed(int(cfg.get("learner_checkpoint_interval") or 0)):
@@ -183,7 +290,7 @@ class Learner:
         return self.core.step >= float(ratio) * max(1, self.ctrl.env_steps)
 
     def _finish(self) -> None:
-        self.publish_weights()
+        self.publish_weights(wait=True)
         self._log_metrics()
         self.ctrl.store(ControlBlock.UPDATE_STEP, self.core.step)
         self._checkpoint(final=True)
@@ -209,7 +316,10 @@ class Learner:
         ingest = RingIngestor(rings, replay, self.device, cfg["ingest_chunk"])
         min_rows = max(int(cfg["min_replay_size"]), int(cfg["batch_size"]))
         ingest_every = max(1, int(cfg.get("ingest_interval", 32)))     # updates between two ring drains
-        self.publish_weights()
+        self.rollout = self._make_rollout(replay)
+        rollout_every = max(1, int(cfg.get("gpu_rollout_interval", 32)))
+        last_rollout = -rollout_every
+        self.publish_weights(wait=True)
         ctrl.store(ControlBlock.LEARNER_ALIVE, 1)
         last_ingest = core.step
         if dp is not None:
@@ -218,10 +328,22 @@ class Learner:
             burst = getattr(core, "update_from_replay_many", None) or (lambda n: core.update_from_replay() and 1)
 
         def extra():
-            return {"data_struct/replay_buffer": float(len(replay)),
-                    "data_struct/replay_queue": float(sum(len(r) for r in rings)),
-                    "data_struct/global_episode": float(ctrl.global_episode),
-                    "data_struct/ring_dropped": float(sum(r.dropped for r in rings))}
+            out = {"data_struct/replay_buffer": float(len(replay)),
+                   "data_struct/replay_queue": float(sum(len(r) for r in rings)),
+                   "data_struct/global_episode": float(ctrl.global_episode),
+                   "data_struct/ring_dropped": float(sum(r.dropped for r in rings))}
+            if self.rollout is not None:
+                mean_ret, n_ep = self.rollout.episode_stats()       # the metrics read-back has synchronised already
+                if n_ep:
+                    ctrl.add(ControlBlock.GLOBAL_EPISODE, n_ep)
+                    out["agent/reward_device_explorers"] = mean_ret
+            return out
+
+        def rollout_segment() -> None:
+            n = self.rollout.collect_overlapped(core.online.flat.data_ptr(), core.layout.actor.base)
+            ctrl.add(ControlBlock.ENV_STEPS, n)
+            if dp is not None:
+                dp.mark_inserted()
 
         # Several learners step in lockstep through their collectives: none may leave on its own.  The stop
         # flag is therefore agreed on (max over ranks of a control scalar) every `control_interval` updates.
@@ -232,9 +354,13 @@ class Learner:
                 moved = ingest.poll()
                 if moved and dp is not None:
                     dp.mark_inserted()
+                if self.rollout is not None:
+                    rollout_segment()
+                    last_rollout = core.step
+                    moved += 1
                 if moved == 0:
                     time.sleep(0.0005)
-                ctrl.heartbeat(0, int(time.time() * 1000))
+                self._beat()
                 if ctrl.stop:            # starved and told to stop: the job is being torn down
                     break
                 continue
@@ -243,6 +369,9 @@ class Learner:
                 last_ingest = prev
                 if ingest.poll() and dp is not None:
                     dp.mark_inserted()
+            if self.rollout is not None and prev - last_rollout >= rollout_every:
+                last_rollout = prev
+                rollout_segment()
             burst(self.num_train_steps - prev)       # one update, or a whole drawn-ahead chunk as one graph
             self._after_update(extra, prev)
             if world > 1 and prev // control_every != core.step // control_every:
@@ -258,10 +387,25 @@ class Learner:
             replay.dump(os.path.join(cfg["results_path"], "replay_buffer.pkl"))
         self._finish()
 
+    def _make_rollout(self, replay):
+        """Explorers resident on this GPU (``gpu_rollout_envs`` > 0 and the environment exists as device
+        kernels): they fill the replay next to, or instead of, the CPU explorer processes."""
+        cfg = self.config
+        n_envs = int(cfg.get("gpu_rollout_envs") or 0)
+        if n_envs <= 0 or self.device.type != "cuda":
+            return None
+        from ..actors.gpu_rollout import DeviceRollout
+        from ..envs.device_pendulum import make_device_env
+        seed = int(cfg["random_seed"]) + 7919 * (self.rank + 1)
+        env = make_device_env(cfg, n_envs, self.device, seed)
+        if env is None:
+            raise ValueError(f"gpu_rollout_envs: no device-resident implementation of '{cfg['env']}'")
+        return DeviceRollout(cfg, env, replay, self.device, segment=int(cfg.get("gpu_rollout_segment", 32)), seed=seed)
+
     # ---------------------------------------------------------------- host path
     def run_host(self, batch_queue, priority_queue=None) -> None:
         cfg, core, ctrl = self.config, self.core, self.ctrl
-        self.publish_weights()
+        self.publish_weights(wait=True)
         ctrl.store(ControlBlock.LEARNER_ALIVE, 1)
         per = bool(cfg["replay_memory_prioritized"])
         while core.step < self.num_train_steps and not ctrl.stop:
@@ -271,7 +415,7 @@ class Learner:
             try:
                 arrays = batch_queue.get(timeout=0.05)
             except queue.Empty:
-                ctrl.heartbeat(0, int(time.time() * 1000))
+                self._beat()
                 continue
             s, a, r, s2, d, g, w, idx = (torch.from_numpy(np.ascontiguousarray(x)) for x in arrays)
             batch = Batch(s.float(), a.float(), r.float(), s2.float(), d.float(), g.float(),

@@ -271,6 +271,8 @@ class ControlBlock(_Shm):
     _detach = "ctrl_detach"
     # fixed slots
     STOP, UPDATE_STEP, GLOBAL_EPISODE, ENV_STEPS, LEARNER_ALIVE, FAILED = range(6)
+    #: device-resident weight hand-off (parallel/hip_ipc.py): completed publications / learner step of the newest
+    GPU_WEIGHT_VERSION, GPU_WEIGHT_STEP = 6, 7
     N_FIXED = 16
 
     @classmethod

@@ -133,3 +133,85 @@ def test_learner_failure_tears_the_job_down(tmp_path, monkeypatch):
     assert e.exit_codes["learner-0"] != 0
     # no process is left behind and the shared segments are gone
     assert not [f for f in os.listdir("/dev/shm") if f.startswith(f"d4pg_") and str(os.getpid()) in f]
+
+
+def _hang_once_agent_worker(*args):
+    """Explorer that beats once and then never returns from its 'environment' on its first start."""
+    import time as _t
+    from d4pg_pytorch_amd import engine as eng
+    from d4pg_pytorch_amd.parallel.ipc import ControlBlock
+    marker = os.path.join(args[0]["results_path"], "hung_once")
+    if args[4] == 1 and not os.path.exists(marker):
+        os.makedirs(os.path.dirname(marker), exist_ok=True)
+        open(marker, "w").close()
+        ctrl = ControlBlock.attach(args[1])
+        ctrl.heartbeat(args[7], int(_t.time() * 1000))
+        _t.sleep(3600)
+    eng.agent_worker(*args)
+
+
+def test_supervisor_replaces_a_hung_explorer(tmp_path, monkeypatch):
+    """A process that stops beating without dying is killed and started again; the job completes."""
+    from d4pg_pytorch_amd import engine as eng
+    monkeypatch.setattr(eng, "agent_worker", _hang_once_agent_worker)
+    cfg = dict(TEST_VALUES, env="Pendulum-v0", model="ddpg", results_path=str(tmp_path / "results"),
+               num_steps_train=60, batch_size=64, heartbeat_timeout_s=1.5)
+    e = Engine(default_config(**cfg))
+    e.train()
+    assert e.hung_killed == 1 and e.restarts == 1 and e.final_update_step == 60
+    assert all(code == 0 for name, code in e.exit_codes.items()), e.exit_codes
+
+
+def _hanging_learner_worker(config, ctrl_name, slab_name, ring_names, log_dir, rank, *rest, **kw):
+    """Learner rank that comes up, beats, and then blocks for good (a peer lost inside a collective)."""
+    import time as _t
+    from d4pg_pytorch_amd.parallel.ipc import ControlBlock
+    ctrl = ControlBlock.attach(ctrl_name)
+    ctrl.store(ControlBlock.LEARNER_ALIVE, 1)
+    ctrl.heartbeat(rank, int(_t.time() * 1000))
+    _t.sleep(3600)
+
+
+def test_hung_learner_tears_the_job_down(tmp_path, monkeypatch):
+    from d4pg_pytorch_amd import engine as eng
+    monkeypatch.setattr(eng, "learner_worker", _hanging_learner_worker)
+    cfg = dict(TEST_VALUES, env="Pendulum-v0", model="d4pg", results_path=str(tmp_path / "results"),
+               heartbeat_timeout_s=1.5)
+    e = Engine(default_config(**cfg))
+    with pytest.raises(RuntimeError, match="training failed"):
+        e.train()
+    assert e.exit_codes["learner-0"] != 0                       # it had to be terminated
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("d4pg_") and str(os.getpid()) in f]
+
+
+def test_supervisor_watches_every_learner_rank():
+    """Any rank of a multi-learner job falling silent ends the job, not only rank 0."""
+    import multiprocessing as mp
+    import time as _t
+    from d4pg_pytorch_amd.parallel.ipc import ControlBlock
+    e = Engine(default_config(**dict(TEST_VALUES, env="Pendulum-v0", model="d4pg", heartbeat_timeout_s=0.5)))
+    ctx = mp.get_context("spawn")
+    with ControlBlock.create(n_workers=8) as ctrl:
+        procs = {f"learner-{r}": ctx.Process(target=_t.sleep, args=(30,)) for r in range(2)}
+        for p in procs.values():
+            p.start()
+        try:
+            e.hb_slots = {"learner-0": 0, "learner-1": 1}
+            ctrl.heartbeat(1, int(_t.time() * 1000) - 10_000)            # rank 1 last beat 10 s ago
+            stop_beating = _t.time() + 20
+
+            def beat():
+                while _t.time() < stop_beating and not ctrl.stop:
+                    ctrl.heartbeat(0, int(_t.time() * 1000))             # rank 0 is healthy
+                    _t.sleep(0.05)
+            import threading
+            th = threading.Thread(target=beat)
+            th.start()
+            t0 = _t.time()
+            e._supervise(ctx, procs, {}, ctrl)
+            th.join()
+            assert ctrl.stop and ctrl.load(ControlBlock.FAILED) == 1 and _t.time() - t0 < 5
+        finally:
+            for p in procs.values():
+                p.kill()
+                p.join()
