@@ -7,6 +7,8 @@
 #include <stdint.h>
 
 #define D4PG_API extern "C" __attribute__((visibility("default")))
+// Size of an argument struct as compiled here; ops/hip.py compares it with its ctypes mirror at load time.
+#define D4PG_SIZEOF(T) D4PG_API int d4pg_sizeof_##T() { return (int)sizeof(T); }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -1444,4 +1444,14 @@ D4PG_API int d4pg_wgrad(WgradGroup* g, hipStream_t stream) {
     if (nwv == 8) return launch_wgrad(wgrad_kernel<8>, 8, base, *g, stream);
     return launch_wgrad(wgrad_kernel<4>, 4, base, *g, stream);
 }
+D4PG_SIZEOF(PackedIn)
+D4PG_SIZEOF(PhaseDims)
+D4PG_SIZEOF(WgradAdam)
+D4PG_SIZEOF(LayerW)
+D4PG_SIZEOF(CriticAhead)
+D4PG_SIZEOF(ActorFwd)
+D4PG_SIZEOF(CriticPhaseArgs)
+D4PG_SIZEOF(ActorPhaseArgs)
+D4PG_SIZEOF(WgradDesc)
+D4PG_SIZEOF(WgradGroup)
 #endif   // D4PG_MAIN_UNIT

@@ -971,15 +971,11 @@ D4PG_API int d4pg_actor_infer32(const ActorInferArgs32* a, int mt, hipStream_t s
     return -10;
 #endif
 }
-D4PG_API int d4pg_sizeof_ActorInferArgs32() { return (int)sizeof(ActorInferArgs32); }
 
 D4PG_API int d4pg_phase32_lds_bytes(const PhaseDims* d, int mt, int actor) {
     return actor ? lds_bytes_actor32(*d, 4 * mt, mt) : lds_bytes_critic32(*d, 4 * mt, mt);
 }
 D4PG_API int d4pg_phase32_waves() { return NW32; }
-D4PG_API int d4pg_sizeof_LayerW32() { return (int)sizeof(LayerW32); }
-D4PG_API int d4pg_sizeof_CriticPhaseArgs32() { return (int)sizeof(CriticPhaseArgs32); }
-D4PG_API int d4pg_sizeof_ActorPhaseArgs32() { return (int)sizeof(ActorPhaseArgs32); }
 
 // ---------------------------------------------------------------------------------------
 // Weight gradients:  dW[o][i] = sum_b dY[b][o] * X[b][i],  db[o] = sum_b dY[b][o]
@@ -1171,5 +1167,11 @@ D4PG_API int d4pg_wgrad32(WgradGroup32* g, hipStream_t stream) {
     if (nwv == 8) return launch_wgrad32(wgrad32_kernel<8>, 8, base, *g, stream);
     return launch_wgrad32(wgrad32_kernel<4>, 4, base, *g, stream);
 }
-D4PG_API int d4pg_sizeof_WgradGroup32() { return (int)sizeof(WgradGroup32); }
+D4PG_SIZEOF(LayerW32)
+D4PG_SIZEOF(ActorFwd32)
+D4PG_SIZEOF(CriticPhaseArgs32)
+D4PG_SIZEOF(ActorPhaseArgs32)
+D4PG_SIZEOF(WgradDesc32)
+D4PG_SIZEOF(WgradGroup32)
+D4PG_SIZEOF(ActorInferArgs32)
 #endif   // D4PG_MAIN_UNIT

@@ -235,3 +235,6 @@ D4PG_API int d4pg_gemm_group(GemmGroup* g, hipStream_t stream) {
     hipLaunchKernelGGL(gemm_group_kernel, dim3(base), dim3(256), 0, stream, *g);
     return (int)hipGetLastError();
 }
+
+D4PG_SIZEOF(GemmDesc)
+D4PG_SIZEOF(GemmGroup)

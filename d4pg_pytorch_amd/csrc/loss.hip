@@ -198,3 +198,8 @@ D4PG_API int d3pg_actor_loss(const D3pgActorLossArgs* a, hipStream_t stream) {
     hipLaunchKernelGGL(d3pg_actor_loss_kernel, dim3((a->B + 255) / 256), dim3(256), 0, stream, *a);
     return (int)hipGetLastError();
 }
+
+D4PG_SIZEOF(D4pgLossArgs)
+D4PG_SIZEOF(D4pgActorLossArgs)
+D4PG_SIZEOF(D3pgLossArgs)
+D4PG_SIZEOF(D3pgActorLossArgs)

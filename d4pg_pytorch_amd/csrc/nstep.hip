@@ -97,3 +97,6 @@ D4PG_API int d4pg_ou_noise(const OuArgs* a, hipStream_t stream) {
     hipLaunchKernelGGL(ou_counter_kernel, dim3(1), dim3(64), 0, stream, a->counter);
     return (int)hipGetLastError();
 }
+
+D4PG_SIZEOF(NstepArgs)
+D4PG_SIZEOF(OuArgs)

@@ -197,3 +197,7 @@ D4PG_API int d4pg_tick(DevState* st, float beta1, float beta2, float per_b0, flo
 }
 
 D4PG_API int d4pg_devstate_size() { return (int)sizeof(DevState); }
+
+D4PG_SIZEOF(ShadowMat)
+D4PG_SIZEOF(ShadowArgs)
+D4PG_SIZEOF(AdamPolyakArgs)

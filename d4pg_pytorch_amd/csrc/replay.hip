@@ -262,3 +262,12 @@ D4PG_API int d4pg_scatter_batch(const ScatterBatchArgs* a, hipStream_t stream) {
     hipLaunchKernelGGL(scatter_batch_kernel, dim3(blocks), dim3(256), 0, stream, *a);
     return (int)hipGetLastError();
 }
+
+D4PG_SIZEOF(TreeDesc)
+D4PG_SIZEOF(ReplayDesc)
+D4PG_SIZEOF(TreeUpdateArgs)
+D4PG_SIZEOF(SampleArgs)
+D4PG_SIZEOF(InsertArgs)
+D4PG_SIZEOF(SampleRowsArgs)
+D4PG_SIZEOF(UnpackArgs)
+D4PG_SIZEOF(ScatterBatchArgs)

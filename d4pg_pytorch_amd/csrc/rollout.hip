@@ -44,7 +44,6 @@ D4PG_API int d4pg_pack_actor32(const PackActorArgs32* a, hipStream_t stream) {
     hipLaunchKernelGGL(pack_actor32_kernel, dim3(160, 3), dim3(256), 0, stream, *a);
     return (int)hipGetLastError();
 }
-D4PG_API int d4pg_sizeof_PackActorArgs32() { return (int)sizeof(PackActorArgs32); }
 
 // ---------------------------------------------------------------------------------------------------
 struct PendulumArgs {
@@ -128,7 +127,6 @@ D4PG_API int d4pg_pendulum_step(const PendulumArgs* a, hipStream_t stream) {
     hipLaunchKernelGGL(rollout_counter_kernel, dim3(1), dim3(64), 0, stream, a->counter);
     return (int)hipGetLastError();
 }
-D4PG_API int d4pg_sizeof_PendulumArgs() { return (int)sizeof(PendulumArgs); }
 
 // ---------------------------------------------------------------------------------------------------
 struct RolloutRowsArgs {
@@ -170,7 +168,6 @@ D4PG_API int d4pg_rollout_rows(const RolloutRowsArgs* a, hipStream_t stream) {
     hipLaunchKernelGGL(rollout_rows_kernel, dim3(blocks), dim3(256), 0, stream, *a);
     return (int)hipGetLastError();
 }
-D4PG_API int d4pg_sizeof_RolloutRowsArgs() { return (int)sizeof(RolloutRowsArgs); }
 
 // ---------------------------------------------------------------------------------------------------
 // Inter-process sharing of a device buffer.  The exporting process allocates with d4pg_ipc_alloc (a
@@ -196,3 +193,8 @@ D4PG_API int d4pg_ipc_free(void* p) { return (int)hipFree(p); }
 D4PG_API int d4pg_memcpy_d2d_async(void* dst, const void* src, size_t bytes, hipStream_t stream) {
     return (int)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream);
 }
+
+D4PG_SIZEOF(PackMat32)
+D4PG_SIZEOF(PackActorArgs32)
+D4PG_SIZEOF(PendulumArgs)
+D4PG_SIZEOF(RolloutRowsArgs)

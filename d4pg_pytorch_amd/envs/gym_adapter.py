@@ -40,20 +40,33 @@ class GymVec(VecEnv):
         super().__init__(env_name, num_envs, state_dim, action_dim, action_low, action_high, seed)
         self.reward_scale = float(reward_scale)
         self.envs = [gym.make(env_name) for _ in range(num_envs)]
-        self._seed = seed
         obs_dim = int(np.prod(self.envs[0].observation_space.shape))
         act_dim = int(np.prod(self.envs[0].action_space.shape))
         if (obs_dim, act_dim) != (state_dim, action_dim):
             raise ValueError(f"{env_name}: env dims ({obs_dim}, {act_dim}) != config ({state_dim}, {action_dim})")
+        self._arm_seeds(seed)
+
+    def _arm_seeds(self, seed) -> None:
+        """Environment ``e`` is seeded with ``seed + e`` ONCE, at its next reset (the reference seeds once at
+        construction, ``env/env_wrapper.py:36-38``); later resets continue that stream, so episodes differ."""
+        self._pending_seed = [None if seed is None else int(seed) + e for e in range(self.num_envs)]
+
+    def set_random_seed(self, seed: int) -> None:
+        super().set_random_seed(seed)
+        self._arm_seeds(seed)
 
     def _reset_env(self, e: int):
         env = self.envs[e]
-        try:
-            out = env.reset(seed=None if self._seed is None else self._seed + e)
-        except TypeError:
-            if self._seed is not None and hasattr(env, "seed"):
-                env.seed(self._seed + e)
+        seed, self._pending_seed[e] = self._pending_seed[e], None
+        if seed is None:
             out = env.reset()
+        else:
+            try:
+                out = env.reset(seed=seed)           # gymnasium / gym >= 0.26
+            except TypeError:
+                if hasattr(env, "seed"):
+                    env.seed(seed)                   # the old API the reference uses
+                out = env.reset()
         obs = out[0] if isinstance(out, tuple) else out
         return np.asarray(obs, np.float32).reshape(-1)
 

@@ -304,8 +304,25 @@ class DevStateMirror(C.Structure):
                 ("pad_", C.c_longlong * 2)]
 
 
-_SIZE_CHECKED = (LayerW32, CriticPhaseArgs32, ActorPhaseArgs32, WgradGroup32, ActorInferArgs32, PackActorArgs32,
-                 PendulumArgs, RolloutRowsArgs)
+def _mirrored_structs():
+    """Every ctypes mirror of a kernel argument struct defined in this module (``DevStateMirror`` has its own
+    check against ``d4pg_devstate_size``)."""
+    return [v for v in globals().values()
+            if isinstance(v, type) and issubclass(v, C.Structure) and v is not C.Structure and v is not DevStateMirror
+            and v.__module__ == __name__]
+
+def check_struct_sizes(lib) -> int:
+    """Compare every argument struct mirrored above with the size the kernels were compiled with: a drifted
+    field would otherwise corrupt GPU memory silently.  Returns the number of structs checked."""
+    n = 0
+    for cls in _mirrored_structs():
+        fn = getattr(lib, "d4pg_sizeof_" + cls.__name__)        # a mirror without an export fails here, loudly
+        fn.restype = C.c_int
+        if fn() != C.sizeof(cls):
+            raise RuntimeError(f"{cls.__name__}: {C.sizeof(cls)} bytes in ops/hip.py, {fn()} in csrc/")
+        n += 1
+    return n
+
 
 # ---------------------------------------------------------------------------
 # loader
@@ -374,13 +391,7 @@ def lib() -> C.CDLL:
         if _lib.d4pg_devstate_size() != C.sizeof(DevStateMirror):
             raise RuntimeError("DevState layout mismatch between csrc/common.h and ops/hip.py")
         _lib.d4pg_phase32_waves.restype = C.c_int
-        # every argument struct mirrored above is checked against the size the kernels were compiled with:
-        # a drifted field would otherwise corrupt GPU memory silently
-        for cls in _SIZE_CHECKED:
-            fn = getattr(_lib, "d4pg_sizeof_" + cls.__name__)
-            fn.restype = C.c_int
-            if fn() != C.sizeof(cls):
-                raise RuntimeError(f"{cls.__name__}: {C.sizeof(cls)} bytes in ops/hip.py, {fn()} in csrc/")
+        check_struct_sizes(_lib)
     return _lib
 
 

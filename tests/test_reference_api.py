@@ -136,3 +136,48 @@ def test_single_env_wrappers():
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         assert EnvWrapper("Hopper-v2", {"state_dim": 11, "action_dim": 3}).reset().shape == (11,)
+
+
+def test_nn_module_front_ends_round_trip_with_the_flat_buffers(tmp_path):
+    """PolicyNetwork / ValueNetwork as ``nn.Module``s (the reference's classes): same attribute names and
+    methods; weights move to and from the learner's flat buffer and the checkpoints on disk."""
+    import torch
+    from d4pg_pytorch_amd.config import default_config
+    from d4pg_pytorch_amd.models import PolicyNetwork, ValueNetwork
+    from d4pg_pytorch_amd.models.core import build_core
+    from d4pg_pytorch_amd.utils.checkpoint import save_actor
+    cfg = default_config(env="LunarLanderContinuous-v2", model="d4pg", device="cpu", dense_size=48, batch_size=16,
+                         v_min=-5.0, v_max=5.0, fused_learner="torch")
+    core = build_core(cfg, "cpu")
+    S, A, Hd = 8, 2, 48
+    pol = PolicyNetwork(S, A, Hd, device="cpu").load_view(core.online.actor)
+    val = ValueNetwork(S, A, Hd, -5.0, 5.0, 51, device="cpu").load_view(core.online.critic)
+    assert isinstance(pol, torch.nn.Module) and [n for n, _ in pol.named_children()] == ["linear1", "linear2", "linear3"]
+    s, a = torch.randn(6, S), torch.rand(6, A) * 2 - 1
+    torch.testing.assert_close(pol(s), core.online.actor.forward(s, "tanh"))
+    torch.testing.assert_close(val(s, a), core.online.critic.forward(torch.cat([s, a], 1), "none"))
+    probs = val.get_probs(s, a)
+    torch.testing.assert_close(probs.sum(1), torch.ones(6))
+    assert val.z_atoms.shape == (51,) and val.z_atoms[0] == -5.0 and val.z_atoms[-1] == 5.0
+    torch.testing.assert_close(val.expected_q(s, a), (probs * torch.linspace(-5, 5, 51)).sum(1))
+    act = pol.get_action(np.zeros(S, np.float32))
+    assert act.shape == (1, A) and act.abs().max() <= 1
+    # module -> flat buffer
+    with torch.no_grad():
+        pol.linear2.bias.add_(0.25)
+    pol.store_view(core.online.actor)
+    torch.testing.assert_close(core.online.actor.biases[1], pol.linear2.bias.detach())
+    # checkpoint on disk -> module
+    path = save_actor(str(tmp_path / "agent_0" / "ckpt.pt"), core.online.actor.state_dict(), {"env": cfg["env"]})
+    loaded = PolicyNetwork.from_checkpoint(path)
+    torch.testing.assert_close(loaded(s), pol(s))
+    # scalar critic (D3PG / DDPG), with the reference's unused batch-norm member for key compatibility
+    q = ValueNetwork(S, A, Hd, device="cpu", batch_norm=True)
+    assert q(s, a).shape == (6, 1) and q.expected_q(s, a).shape == (6,)
+    assert {"bn1.weight", "linear3.bias"} <= set(q.state_dict())
+    with pytest.raises(ValueError):
+        q.get_probs(s, a)
+    with pytest.raises(ValueError):
+        ValueNetwork(S, A, Hd, num_atoms=51)
+    fresh = PolicyNetwork(S, A, Hd, init_w=3e-3, device="cpu")
+    assert fresh.linear3.weight.abs().max() <= 3e-3 and fresh.linear3.bias.abs().max() <= 3e-3
