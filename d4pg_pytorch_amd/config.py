@@ -114,6 +114,8 @@ EXTENSION_DEFAULTS: Dict[str, Any] = {
     "ring_capacity": 4096,           # rows per explorer->replay shared-memory ring
     "ingest_chunk": 1024,            # rows per pinned H2D staging chunk
     "ingest_interval": 32,           # learner updates between two drains of the explorer rings
+    "ring_dma": True,                # DMA rows straight out of the explorers' shared-memory rings (registered with the
+                                     # HIP runtime); False: pop into a pinned staging buffer first
     "phase_tile_rows": "auto",       # batch rows per phase workgroup: "auto" | 4 | 8 | 16 (fp32) | 16 | 32 (bf16)
     "sample_ahead": 32,              # uniform replay, fused pipelines: batches drawn per sampling launch = updates per
                                      # graph replay (1: every update); 8: 55.3 us per update, 32: 54.4 us
@@ -166,7 +168,7 @@ _FLOAT_KEYS = {
 }
 _BOOL_KEYS = {
     "use_per_sample_gamma", "scale_action", "lossless_replay_queue", "use_hip_graph",
-    "synthetic_env", "check_rings", "share_weights_ipc",
+    "synthetic_env", "check_rings", "share_weights_ipc", "ring_dma",
 }
 
 

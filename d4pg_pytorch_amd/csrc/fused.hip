@@ -513,7 +513,7 @@ __device__ __forceinline__ void critic_rows(const CriticPhaseArgs& a, int row0, 
                 }
             }
             if (lane == 0) {
-                a.per_loss[b] = loss;
+                a.per_loss[b] = loss * (scale / d.inv_B);      // weighted: the finishing role sums it as is
                 a.priority[b] = fabsf(loss) + 1e-4f;
             }
             if (r == 0) STAMP(0, 18);
@@ -526,7 +526,7 @@ __device__ __forceinline__ void critic_rows(const CriticPhaseArgs& a, int row0, 
             const __bf16 v = (__bf16)(2.f * diff * scale);
             dlg[r * d.ldd] = v;
             a.dlT[stash_off(0, b, d.Bp)] = v;
-            a.per_loss[b] = l;
+            a.per_loss[b] = l * (scale / d.inv_B);
             a.priority[b] = fabsf(l) + 1e-4f;
         }
     }
@@ -915,7 +915,7 @@ __global__ __launch_bounds__(64 * NW) void actor_phase_kernel(const ActorPhaseAr
     const int row0 = blockIdx.x * M;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n_tree = a.tree.n > 0 ? 1 : 0;
+    const int n_tree = a.tree.n > 0 ? (a.tree.parts > 1 ? a.tree.parts : 1) : 0;
     const int n_work = d.B / M + n_tree + (a.ahead.mode != 0 ? d.B / M : 0);
     if ((int)blockIdx.x >= n_work) {                // L2 warmers
         const int sl = (blockIdx.x - n_work) >> 3, nsl = (gridDim.x - n_work + 7) >> 3;
@@ -936,7 +936,7 @@ __global__ __launch_bounds__(64 * NW) void actor_phase_kernel(const ActorPhaseAr
         return;
     }
     if (row0 >= d.B) {         // the extra workgroup
-        tree_update_body<NW>(a.tree);
+        tree_update_body<NW>(a.tree, (int)blockIdx.x - d.B / M, (int*)smem);
         return;
     }
     STAMP(1, 31);
@@ -1178,7 +1178,8 @@ D4PG_API int d4pg_actor_phase(const ActorPhaseArgs* a, int mt, hipStream_t strea
     if (check_hidden(a->cb2, ksh_) || check_hidden(a->cb1, ksh_) || check_hidden(a->ab2, ksh_)) return -10;
     const int ksn = max3i(a->cf[0].ks, a->cb3.ks, a->ab3.ks);
     if (a->tree.n < 0 || (a->tree.n > 0 && (a->tree.idx == nullptr || a->tree.prio == nullptr ||
-                                            a->tree.t.L < 0 || a->tree.t.L > MAXL)))
+                                            a->tree.t.L < 0 || a->tree.t.L > MAXL || a->tree.parts > 64 ||
+                                            (a->tree.parts > 1 && (a->tree.t.L < 2 || a->tree.ticket == nullptr)))))
         return -11;
     if (a->ahead.mode != 0) {
         if (a->ahead.mode < 0 || a->ahead.mode > 2 || !a->pk.enabled) return -15;
@@ -1188,7 +1189,7 @@ D4PG_API int d4pg_actor_phase(const ActorPhaseArgs* a, int mt, hipStream_t strea
         if (int prc = check_packed(a->pk, a->d)) return prc;
     }
     const int n_ahead = a->ahead.mode != 0 ? a->d.B / (mt == 2 ? 32 : 16) : 0;
-    const int extra_blocks = (a->tree.n > 0 ? 1 : 0) + n_ahead + n_warmers(a->d, mt);
+    const int extra_blocks = (a->tree.n > 0 ? (a->tree.parts > 1 ? a->tree.parts : 1) : 0) + n_ahead + n_warmers(a->d, mt);
     DISPATCH_PHASE(launch_actor_ksh, phase_lds_bytes_actor)
 }
 

@@ -257,7 +257,7 @@ __device__ __forceinline__ void critic_rows(const PhaseDims& d, const CriticRows
                 }
             }
             if (lane == 0) {
-                a.per_loss[b] = loss;
+                a.per_loss[b] = loss * (scale / d.inv_B);      // weighted: the finishing role sums it as is
                 a.priority[b] = fabsf(loss) + 1e-4f;
             }
         } else if (lane == 0) {
@@ -268,7 +268,7 @@ __device__ __forceinline__ void critic_rows(const PhaseDims& d, const CriticRows
             const float v = 2.f * diff * scale;
             dlg[r * d.ldd] = v;
             a.dlT[stash32_off(0, b, d.Bp)] = v;
-            a.per_loss[b] = l;
+            a.per_loss[b] = l * (scale / d.inv_B);
             a.priority[b] = fabsf(l) + 1e-4f;
         }
     }
@@ -619,7 +619,7 @@ __global__ __launch_bounds__(64 * NW32) void actor_phase32_kernel(const ActorPha
     const int row0 = blockIdx.x * M;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n_tree = a.tree.n > 0 ? 1 : 0;
+    const int n_tree = a.tree.n > 0 ? (a.tree.parts > 1 ? a.tree.parts : 1) : 0;
     const int n_work = d.B / M + n_tree + (a.ahead.mode != 0 ? d.B / M : 0);
     if ((int)blockIdx.x >= n_work) {                // L2 warmers
         const int sl = (blockIdx.x - n_work) >> 3, nsl = (gridDim.x - n_work + 7) >> 3;
@@ -640,7 +640,7 @@ __global__ __launch_bounds__(64 * NW32) void actor_phase32_kernel(const ActorPha
         return;
     }
     if (row0 >= d.B) {         // the extra workgroup: priorities back into the tree
-        tree_update_body<NW32>(a.tree);
+        tree_update_body<NW32>(a.tree, (int)blockIdx.x - d.B / M, (int*)smem);
         return;
     }
     STAMP(1, 31);
@@ -932,7 +932,8 @@ D4PG_API int d4pg_actor_phase32(const ActorPhaseArgs32* a, int mt, hipStream_t s
     if (int rc = check_layer32(a->ab2, 0, ksh, ksn, d.ldh)) return rc;
     if (a->g_xin == nullptr || a->g_h1 == nullptr || a->g_h2 == nullptr) return -14;
     if (a->tree.n < 0 || (a->tree.n > 0 && (a->tree.idx == nullptr || a->tree.prio == nullptr || a->tree.t.L < 0 ||
-                                            a->tree.t.L > MAXL)))
+                                            a->tree.t.L > MAXL || a->tree.parts > 64 ||
+                                            (a->tree.parts > 1 && (a->tree.t.L < 2 || a->tree.ticket == nullptr)))))
         return -11;
     if (a->ahead.mode != 0) {
         if (a->ahead.mode < 0 || a->ahead.mode > 2 || !a->pk.enabled) return -15;
@@ -942,7 +943,7 @@ D4PG_API int d4pg_actor_phase32(const ActorPhaseArgs32* a, int mt, hipStream_t s
         if (int prc = check_packed(a->pk, d)) return prc;
     }
     const int n_ahead = a->ahead.mode != 0 ? d.B / M : 0;
-    const int extra_blocks = (a->tree.n > 0 ? 1 : 0) + n_ahead + n_warmers32(d, M);
+    const int extra_blocks = (a->tree.n > 0 ? (a->tree.parts > 1 ? a->tree.parts : 1) : 0) + n_ahead + n_warmers32(d, M);
     DISPATCH_PHASE32(launch_actor32_ksh, lds_bytes_actor32)
 }
 

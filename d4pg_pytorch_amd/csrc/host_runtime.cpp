@@ -326,6 +326,25 @@ API int64_t ring_peek(void* h, uint64_t* row_offset, int64_t max_rows) {
     return (int64_t)avail;
 }
 
+// The same for a consumer that has spans in flight (handed to a DMA engine, not yet released): the first
+// contiguous readable span that starts `ahead` rows past the read cursor.
+API int64_t ring_peek_from(void* h, uint64_t ahead, uint64_t* row_offset, int64_t max_rows) {
+    auto* r = static_cast<Ring*>(h);
+    RingHeader* hd = r->hdr;
+    const uint64_t rd = hd->read_idx.load(std::memory_order_relaxed) + ahead;
+    const uint64_t w = hd->write_idx.load(std::memory_order_acquire);
+    if (w <= rd) {
+        *row_offset = 0;
+        return 0;
+    }
+    uint64_t avail = w - rd;
+    const uint64_t pos = rd % hd->capacity;
+    if (avail > hd->capacity - pos) avail = hd->capacity - pos;
+    if ((int64_t)avail > max_rows) avail = (uint64_t)max_rows;
+    *row_offset = pos;
+    return (int64_t)avail;
+}
+
 API void ring_advance(void* h, int64_t rows) {
     auto* r = static_cast<Ring*>(h);
     ring_verify(r, r->hdr->read_idx.load(std::memory_order_relaxed), (uint64_t)rows);

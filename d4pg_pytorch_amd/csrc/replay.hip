@@ -72,11 +72,20 @@ D4PG_API int d4pg_replay_insert(const InsertArgs* a, hipStream_t stream) {
 // Tree update as a stand-alone launch (one workgroup of 16 waves); the body lives in
 // replay_dev.h because the fused bf16 pipeline runs it as an extra workgroup of its actor
 // phase kernel.
-__global__ __launch_bounds__(1024) void tree_update_kernel(const TreeUpdateArgs a) { tree_update_body<16>(a); }
+__global__ __launch_bounds__(1024) void tree_update_kernel(const TreeUpdateArgs a) {
+    __shared__ int flag;
+    tree_update_body<16>(a, blockIdx.x, &flag);
+}
 
+// parts > 1 (several workgroups, csrc/replay_dev.h) needs a tree of at least three levels and the ticket counter
+D4PG_API int d4pg_tree_update_check(const TreeUpdateArgs* a) {
+    if (a->n < 1 || a->t.L < 0 || a->t.L > MAXL || a->idx == nullptr || a->prio == nullptr) return -1;
+    if (a->parts > 64 || (a->parts > 1 && (a->t.L < 2 || a->ticket == nullptr))) return -2;
+    return 0;
+}
 D4PG_API int d4pg_tree_update(const TreeUpdateArgs* a, hipStream_t stream) {
-    if (a->n < 1 || a->t.L < 0 || a->t.L > MAXL) return -1;
-    hipLaunchKernelGGL(tree_update_kernel, dim3(1), dim3(1024), 0, stream, *a);
+    if (int rc = d4pg_tree_update_check(a)) return rc;
+    hipLaunchKernelGGL(tree_update_kernel, dim3(a->parts > 1 ? a->parts : 1), dim3(1024), 0, stream, *a);
     return (int)hipGetLastError();
 }
 

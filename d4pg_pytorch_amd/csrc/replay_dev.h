@@ -44,27 +44,45 @@ __device__ __forceinline__ double wave_scan_incl_d(double v, int lane) {
 }
 
 // ---------------------------------------------------------------------------
-// Tree update: leaf[idx[i]] = priority[i]^alpha, then recompute every touched
-// ancestor level by level.  One workgroup (16 waves); __syncthreads() between
-// levels orders the global writes of one level before the reads of the next.
+// Tree update: leaf[idx[i]] = priority[i]^alpha, then recompute every touched ancestor level by level
+// (recomputed from the children, so the fp64 sums never drift).
+//
+// `parts` workgroups share the work by OWNERSHIP of subtrees: the node of level L-1 above an item
+// (idx >> 6(L-1)) belongs to workgroup (node % parts), and so does everything below it.  A workgroup
+// therefore only ever reads what it wrote itself (or what no one writes): leaf writes and levels
+// 1 .. L-1 need no synchronisation between workgroups, only __syncthreads() between the levels.  The top
+// level (at most 64 nodes) is recomputed by whichever workgroup finishes last (ticket counter behind a
+// __threadfence(), children read at device scope): nobody waits for anybody.
 struct TreeUpdateArgs {
     TreeDesc t;
     const long long* idx;   // [n]
     const float* prio;      // [n] raw priorities
     DevState* st;
+    unsigned int* ticket;   // parts > 1: zero-initialised counter, left at zero again
     int n;
     float alpha;
+    int parts;              // workgroups that call tree_update_body (1 .. 64); > 1 needs t.L >= 2
+    int pad_;
 };
 
-// NWAVES = waves of the calling workgroup (all of them must call this)
+// NWAVES = waves of the calling workgroup (all of them must call this); part = 0 .. a.parts - 1;
+// flag = one int of LDS
 template <int NWAVES>
-__device__ __forceinline__ void tree_update_body(const TreeUpdateArgs& a) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__device__ __forceinline__ void tree_update_body(const TreeUpdateArgs& a, int part, int* flag) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int W = a.parts > 1 ? a.parts : 1;
+    const int L = a.t.L;
+    const int top_shift = 6 * (L > 1 ? L - 1 : 0);
+    auto mine = [&](long long node, int level) {          // level <= L-1
+        return W == 1 || (int)((node >> (top_shift - 6 * level)) % W) == part;
+    };
     float local_max = 0.f;
     for (int i = tid; i < a.n; i += 64 * NWAVES) {
+        const long long slot = a.idx[i];
+        if (!mine(slot, 0)) continue;
         float p = a.prio[i];
         if (!(p > 0.f) || p > 3.0e38f) p = 1e-4f;   // NaN / inf / non-positive never enter the tree
-        a.t.leaf[a.idx[i]] = powf(p, a.alpha);
+        a.t.leaf[slot] = powf(p, a.alpha);
         local_max = fmaxf(local_max, p);
     }
     local_max = wave_max(local_max);
@@ -79,12 +97,27 @@ __device__ __forceinline__ void tree_update_body(const TreeUpdateArgs& a) {
     // nodes than the batch has items is recomputed whole (the top level: 4 nodes for 1M rows).
     typedef double f64x2 __attribute__((ext_vector_type(2)));
     const int nthreads = 64 * NWAVES;
-    for (int l = 1; l <= a.t.L; ++l) {
+    for (int l = 1; l <= L; ++l) {
         const long long nodes = a.t.n[l - 1] >> 6;       // nodes of this level that have children (levels are padded)
-        const bool whole = nodes * 8 <= (long long)a.n;
+        const bool top = l == L && W > 1;
+        if (top) {
+            // everything this workgroup wrote is visible device-wide before its ticket is
+            __threadfence();
+            __syncthreads();
+            if (tid == 0) {
+                const unsigned int t = atomicAdd(a.ticket, 1u);
+                *flag = t == (unsigned int)(W - 1);
+                if (*flag) *a.ticket = 0u;             // ready for the next update (stream order)
+            }
+            __syncthreads();
+            if (!*flag) return;
+            __threadfence();
+        }
+        const bool whole = top || nodes * 8 <= (long long)a.n;
         const int tasks = whole ? (int)nodes : a.n;
         for (int i = tid; i < tasks; i += nthreads) {
             const long long g = whole ? (long long)i : (a.idx[i] >> (6 * l));
+            if (!top && !mine(g, l)) continue;
             double s = 0.0;
             float m = INFINITY;
             if (l == 1) {
@@ -99,6 +132,14 @@ __device__ __forceinline__ void tree_update_body(const TreeUpdateArgs& a) {
                         s += (double)v[k][e];
                         m = fminf(m, v[k][e] > 0.f ? v[k][e] : INFINITY);
                     }
+                }
+            } else if (top) {
+                // children written by other workgroups (other CUs): read past this CU's vector cache
+                const double* cs = a.t.sum[l - 1] + g * 64;
+                const float* cm = a.t.mn[l - 1] + g * 64;
+                for (int k = 0; k < 64; ++k) {
+                    s += __hip_atomic_load(cs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    m = fminf(m, __hip_atomic_load(cm + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                 }
             } else {
                 const f64x2* cs = reinterpret_cast<const f64x2*>(a.t.sum[l - 1] + g * 64);

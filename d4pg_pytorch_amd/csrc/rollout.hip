@@ -194,6 +194,18 @@ D4PG_API int d4pg_memcpy_d2d_async(void* dst, const void* src, size_t bytes, hip
     return (int)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream);
 }
 
+// Host memory that is not HIP's own (the explorers' POSIX shared-memory rings) made visible to the copy
+// engines, so that rows go ring -> HBM with one DMA and no staging memcpy on the host.
+D4PG_API int d4pg_host_register(void* p, size_t bytes) {
+    const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) (void)hipGetLastError();      // a refusal is an answer, not an error to leave behind for the next launch check
+    return (int)e;
+}
+D4PG_API int d4pg_host_unregister(void* p) { return (int)hipHostUnregister(p); }
+D4PG_API int d4pg_memcpy_h2d_async(void* dst, const void* src, size_t bytes, hipStream_t stream) {
+    return (int)hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream);
+}
+
 D4PG_SIZEOF(PackMat32)
 D4PG_SIZEOF(PackActorArgs32)
 D4PG_SIZEOF(PendulumArgs)

@@ -163,22 +163,33 @@ class HipCoreBf16(HipCore):
         if ahead is not None:
             return ahead.update()
         if self._per_sampling_rides_along():
-            if self.use_graph and "replay" not in self._graphs:
-                # the warm-up run of the capture works on (and overwrites) the input buffers
-                self.replay.enqueue_sample(self, do_tick=False)
-                self._graphs["replay"] = self._capture(self._segments("replay"), fused=True, reps=1)
-                self._presampled_step = -1
-            if self._presampled_step != self.step:        # first update, or the state was reset / reloaded
-                self.replay.enqueue_sample(self, do_tick=False)
-            self._run("replay")
-            self.step += 1
-            self._presampled_step = self.step
+            self._per_run(1)
             return self.prio
         return super().update_from_replay()
+
+    def _per_run(self, reps: int) -> None:
+        """``reps`` prioritised updates as one graph replay.  Every update draws the batch of the next one in its
+        last launch, behind its own priority write-back, so a chain of updates needs nothing from the host."""
+        key = "replay" + (f"/x{reps}" if reps > 1 else "")
+        if self.use_graph and key not in self._graphs:
+            # the warm-up run of the capture works on (and overwrites) the input buffers
+            self.replay.enqueue_sample(self, do_tick=False)
+            self._graphs[key] = self._capture(self._segments("replay"), fused=True, reps=reps)
+            self._presampled_step = -1
+        if self._presampled_step != self.step:        # first update, or the state was reset / reloaded
+            self.replay.enqueue_sample(self, do_tick=False)
+        self._run("replay", reps)
+        self.step += reps
+        self._presampled_step = self.step
 
     def update_from_replay_many(self, n: int) -> int:
         """Up to ``n`` updates in one call: a whole drawn-ahead chunk of batches is ONE graph replay."""
         ahead = getattr(self, "_ahead", None)
+        if ahead is None and self._per_sampling_rides_along():
+            chunk = max(1, int(self.cfg.get("sample_ahead", 32)))
+            reps = chunk if (n >= chunk and self.use_graph) else 1
+            self._per_run(reps)
+            return reps
         if ahead is None:
             self.update_from_replay()      # creates the draw-ahead driver when it applies
             return 1
@@ -265,7 +276,9 @@ class HipCoreBf16(HipCore):
             o.p_shadow, o.t_shadow = self.shadow_online.data_ptr(), self.shadow_target.data_ptr()
             o.st = self.dev_state.data_ptr()
             o.metrics = self.metrics.data_ptr() if finish else None
-            o.per_loss, o.weights, o.q_val = self.per_loss.data_ptr(), self.weights.data_ptr(), self.q_val.data_ptr()
+            # the critic phase stores the importance-weighted per-row loss: the finishing role must not read
+            # `weights`, which the sampling role of the same launch is refilling for the next update
+            o.per_loss, o.weights, o.q_val = self.per_loss.data_ptr(), None, self.q_val.data_ptr()
             o.B, o.inv_B = self.B, 1.0 / self.B
             o.lr, o.beta1, o.beta2, o.eps, o.tau = lr, self.betas[0], self.betas[1], self.eps, self.tau
             o.finish_step = 1 if finish else 0
@@ -312,7 +325,7 @@ class HipCoreBf16(HipCore):
             a.lr, a.beta1, a.beta2, a.eps, a.tau = lr, b1, b2, self.eps, self.tau
             a.gscale, a.finish_step = 1.0, finish
             a.metrics = self.metrics.data_ptr() if finish else None
-            a.per_loss, a.weights, a.q_val = self.per_loss.data_ptr(), self.weights.data_ptr(), self.q_val.data_ptr()
+            a.per_loss, a.weights, a.q_val = self.per_loss.data_ptr(), None, self.q_val.data_ptr()   # per_loss is weighted
             a.B, a.inv_B = self.B, 1.0 / self.B
             a.sh = self._shadow_args(net, slots, net.base)
             return a

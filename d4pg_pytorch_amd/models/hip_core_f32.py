@@ -142,7 +142,9 @@ class HipCoreF32(HipCoreBf16):
             o.p_shadow, o.t_shadow = self.shadow_online.data_ptr(), self.shadow_target.data_ptr()
             o.st = self.dev_state.data_ptr()
             o.metrics = self.metrics.data_ptr() if finish else None
-            o.per_loss, o.weights, o.q_val = self.per_loss.data_ptr(), self.weights.data_ptr(), self.q_val.data_ptr()
+            # the critic phase stores the importance-weighted per-row loss: the finishing role must not read
+            # `weights`, which the sampling role of the same launch is refilling for the next update
+            o.per_loss, o.weights, o.q_val = self.per_loss.data_ptr(), None, self.q_val.data_ptr()
             o.B, o.inv_B = self.B, 1.0 / self.B
             o.lr, o.beta1, o.beta2, o.eps, o.tau = lr, self.betas[0], self.betas[1], self.eps, self.tau
             o.finish_step = 1 if finish else 0

@@ -39,29 +39,103 @@ from .core import Batch, build_core
 class RingIngestor:
     """Moves transition rows from explorer rings into an HBM replay shard.
 
-    One ``poll`` drains every ring into ONE pinned staging buffer (C++ ``ring_pop`` per ring,
-    no per-row Python), issues one async H2D copy and one ``replay_insert`` launch per
-    ``ingest_chunk`` rows.  Three staging buffers rotate so the host never waits for a copy
-    that is still in flight."""
+    Zero-copy (the default on a GPU): the rings' shared-memory data areas are registered with the HIP runtime
+    once, so a ``poll`` is, per ring, one ``ring_peek`` (no copy) and one asynchronous DMA from the ring's own
+    memory into a device staging block, followed by one ``replay_insert`` launch for all rings.  The rows stay
+    owned by their ring until the DMA's event has completed; only then does ``ring_advance`` hand the slots back
+    to the explorer (polled, the learner never waits).
 
-    def __init__(self, rings: List[ShmRing], replay, device, chunk: int, n_buffers: int = 3):
+    Fallback (registration refused, or ``zero_copy=False``): every ring is drained with ``ring_pop`` into one
+    pinned staging buffer (three rotate) and copied from there."""
+
+    def __init__(self, rings: List[ShmRing], replay, device, chunk: int, n_buffers: int = 3, zero_copy: bool = True):
         self.rings, self.replay, self.device = rings, replay, device
         self.chunk = int(chunk)
         self.cap = max(self.chunk, min(8 * self.chunk, 16384))      # rows per poll over all rings
-        self.pinned = [torch.zeros(self.cap, replay.row_ld).pin_memory() for _ in range(n_buffers)]
-        self.pinned_np = [p.numpy() for p in self.pinned]
         self.staged = [torch.zeros(self.cap, replay.row_ld, device=device) for _ in range(n_buffers)]
-        self.events = [None] * n_buffers
         self._next = 0
         self.rows_ingested = 0
+        self.zero_copy = bool(zero_copy) and bool(rings) and self._register()
+        if self.zero_copy:
+            self.ahead = [0] * len(rings)          # rows peeked and in flight, per ring
+            self.inflight: List = []               # (event, [(ring index, rows), ...]) oldest first
+        else:
+            self.pinned = [torch.zeros(self.cap, replay.row_ld).pin_memory() for _ in range(n_buffers)]
+            self.pinned_np = [p.numpy() for p in self.pinned]
+            self.events = [None] * n_buffers
+
+    def _register(self) -> bool:
+        from ..ops import hip as H
+        done = []
+        for r in self.rings:
+            if H.lib().d4pg_host_register(r.data_ptr, r.data_bytes) != 0:
+                for q in done:
+                    H.lib().d4pg_host_unregister(q.data_ptr)
+                print("[learner] ring memory could not be registered for DMA; staging through pinned buffers", flush=True)
+                return False
+            done.append(r)
+        return True
+
+    def close(self) -> None:
+        if self.zero_copy:
+            from ..ops import hip as H
+            self.release(block=True)
+            for r in self.rings:
+                H.lib().d4pg_host_unregister(r.data_ptr)
+            self.zero_copy = False
+
+    def release(self, block: bool = False) -> None:
+        """Give the slots of completed DMAs back to their rings."""
+        while self.inflight:
+            ev, spans = self.inflight[0]
+            if block:
+                ev.synchronize()
+            elif not ev.query():
+                return
+            for k, n in spans:
+                self.rings[k].advance(n)
+                self.ahead[k] -= n
+            self.inflight.pop(0)
+
+    def _poll_zero_copy(self, per_ring: int) -> int:
+        from ..ops import hip as H
+        self.release()
+        i = self._next
+        dst, row_bytes = self.staged[i], self.replay.row_ld * 4
+        stream = H.stream_ptr()
+        n, spans = 0, []
+        for k, ring in enumerate(self.rings):
+            taken = 0
+            while taken < per_ring and n < self.cap:        # at most two spans: the readable part may wrap
+                off, m = ring.peek(min(per_ring - taken, self.cap - n), ahead=self.ahead[k])
+                if m == 0:
+                    break
+                H._check(H.lib().d4pg_memcpy_h2d_async(dst[n:].data_ptr(), ring.data_ptr + off * row_bytes,
+                                                       m * row_bytes, stream), "d4pg_memcpy_h2d_async")
+                self.ahead[k] += m
+                spans.append((k, m))
+                taken += m
+                n += m
+        if n == 0:
+            return 0
+        # staged[i] is rewritten n_buffers polls later, on the same stream, i.e. behind this insert
+        self.replay.insert(dst[:n])
+        ev = torch.cuda.Event()
+        ev.record()
+        self.inflight.append((ev, spans))
+        self._next = (i + 1) % len(self.staged)
+        self.rows_ingested += n
+        return n
 
     def poll(self, max_chunks_per_ring: int = 4) -> int:
+        per_ring = max_chunks_per_ring * self.chunk
+        if self.zero_copy:
+            return self._poll_zero_copy(per_ring)
         i = self._next
         if self.events[i] is not None:
             self.events[i].synchronize()          # the previous H2D out of this pinned buffer is done
         buf = self.pinned_np[i]
         n = 0
-        per_ring = max_chunks_per_ring * self.chunk
         for ring in self.rings:
             room = min(per_ring, self.cap - n)
             if room <= 0:
@@ -313,7 +387,7 @@ class Learner:
         else:
             core.attach_replay(replay)
         self.replay = replay
-        ingest = RingIngestor(rings, replay, self.device, cfg["ingest_chunk"])
+        ingest = RingIngestor(rings, replay, self.device, cfg["ingest_chunk"], zero_copy=bool(cfg.get("ring_dma", True)))
         min_rows = max(int(cfg["min_replay_size"]), int(cfg["batch_size"]))
         ingest_every = max(1, int(cfg.get("ingest_interval", 32)))     # updates between two ring drains
         self.rollout = self._make_rollout(replay)
@@ -379,6 +453,7 @@ class Learner:
                     break
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
+        ingest.close()
         if dp is not None:
             drift = dp.check_consistency()
             if drift != 0.0:

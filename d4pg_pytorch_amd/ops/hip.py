@@ -111,8 +111,8 @@ class InsertArgs(C.Structure):
 
 
 class TreeUpdateArgs(C.Structure):
-    _fields_ = [("t", TreeDesc), ("idx", vp), ("prio", vp), ("st", vp), ("n", C.c_int),
-                ("alpha", C.c_float)]
+    _fields_ = [("t", TreeDesc), ("idx", vp), ("prio", vp), ("st", vp), ("ticket", vp), ("n", C.c_int),
+                ("alpha", C.c_float), ("parts", C.c_int), ("pad_", C.c_int)]
 
 
 class SampleArgs(C.Structure):
@@ -380,6 +380,9 @@ def lib() -> C.CDLL:
             ("d4pg_ipc_close", [vp]),
             ("d4pg_ipc_free", [vp]),
             ("d4pg_memcpy_d2d_async", [vp, vp, C.c_size_t, vp]),
+            ("d4pg_memcpy_h2d_async", [vp, vp, C.c_size_t, vp]),
+            ("d4pg_host_register", [vp, C.c_size_t]),
+            ("d4pg_host_unregister", [vp]),
         ):
             fn = getattr(_lib, name)
             fn.argtypes = argt

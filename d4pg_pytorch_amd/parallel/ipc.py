@@ -48,6 +48,7 @@ def host_lib() -> C.CDLL:
             "ring_pushed_total": (u64, [vp]), "ring_close": (None, [vp]), "ring_is_closed": (C.c_int, [vp]),
             "ring_push": (i64, [vp, vp, i64, i64]), "ring_pop": (i64, [vp, vp, i64]),
             "ring_peek": (i64, [vp, C.POINTER(u64), i64]), "ring_advance": (None, [vp, i64]),
+            "ring_peek_from": (i64, [vp, u64, C.POINTER(u64), i64]),
             "ring_set_check": (None, [vp, C.c_int]), "ring_seq_errors": (u64, [vp]),
             "slab_create": (vp, [C.c_char_p, u64]), "slab_attach": (vp, [C.c_char_p]),
             "slab_detach": (None, [vp]), "slab_data_ptr": (vp, [vp]), "slab_n_floats": (u64, [vp]),
@@ -177,10 +178,14 @@ class ShmRing(_Shm):
         n = host_lib().ring_pop(self._h, np_ptr(out), min(max_rows, out.shape[0]))
         return out[:n]
 
-    def peek(self, max_rows: int) -> Tuple[int, int]:
-        """(row offset into the data area, contiguous row count) without consuming."""
+    def peek(self, max_rows: int, ahead: int = 0) -> Tuple[int, int]:
+        """(row offset into the data area, contiguous row count) without consuming.  ``ahead``: rows past the
+        read cursor that were peeked before and are still waiting for :meth:`advance` (a DMA in flight)."""
         off = u64(0)
-        n = host_lib().ring_peek(self._h, C.byref(off), max_rows)
+        if ahead:
+            n = host_lib().ring_peek_from(self._h, int(ahead), C.byref(off), max_rows)
+        else:
+            n = host_lib().ring_peek(self._h, C.byref(off), max_rows)
         return off.value, n
 
     def advance(self, rows: int) -> None:

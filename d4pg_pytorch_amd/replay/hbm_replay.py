@@ -89,6 +89,7 @@ class HbmReplay:
                               for n in self.level_sizes[1:]]
         self.mins = [None] + [torch.full((n,), float("inf"), dtype=torch.float32, device=self.device)
                               for n in self.level_sizes[1:]]
+        self._ticket = torch.zeros(1, dtype=torch.int32, device=self.device)      # multi-workgroup tree updates
 
     # ------------------------------------------------------------ descriptors
     def _replay_desc(self) -> H.ReplayDesc:
@@ -193,11 +194,20 @@ class HbmReplay:
         a.step = int(step)
         H.launch("d4pg_replay_sample_rows", a, stream)
 
+    def tree_parts(self, n: int) -> int:
+        """Workgroups that share a priority update of ``n`` items (``tree_update_body`` in ``csrc/replay_dev.h``:
+        subtrees of the level below the top are dealt to the workgroups): one per 512 items, at most 8, and
+        only for trees of three levels or more."""
+        if self.L < 2 or n < 1024:
+            return 1
+        return int(min(8, n // 512))
+
     def priority_update_args(self, idx: torch.Tensor, prio: torch.Tensor, n: int) -> H.TreeUpdateArgs:
         a = H.TreeUpdateArgs()
         a.t = self._tree_desc()
         a.idx, a.prio, a.st = idx.data_ptr(), prio.data_ptr(), self.dev_state.data_ptr()
         a.n, a.alpha = int(n), self.alpha
+        a.parts, a.ticket = self.tree_parts(int(n)), self._ticket.data_ptr()
         return a
 
     def enqueue_priority_update(self, idx: torch.Tensor, prio: torch.Tensor, n: int, stream=None) -> None:

@@ -139,6 +139,40 @@ def test_per_tree_matches_brute_force_and_is_weights():
     assert chi2 < 80, chi2           # stratified sampling has lower variance than multinomial
 
 
+@pytest.mark.parametrize("capacity,n_items", [(300_000, 4096), (300_000, 8192), (70_000, 2048), (1_000_000, 4096)])
+def test_tree_update_shared_by_several_workgroups(capacity, n_items):
+    """Large priority write-backs are dealt to up to 8 workgroups by subtree ownership; the tree they leave
+    equals a rebuild from the leaves, duplicates and repeated updates included."""
+    cfg, core, rp = _mk(capacity=capacity, per=True, B=256)
+    assert rp.L >= 2 and rp.tree_parts(n_items) == min(8, n_items // 512) > 1
+    n = min(capacity, 250_000)
+    for off in range(0, n, 50_000):
+        rp.insert(_rows(rp, min(50_000, n - off)))
+    g = torch.Generator().manual_seed(1)
+    leaf = torch.ones(n, dtype=torch.float64)
+    for rnd in range(4):
+        idx = torch.randint(0, n, (n_items,), generator=g)
+        if rnd == 1:
+            idx[: n_items // 2] = idx[n_items // 2:]                 # every item twice, with the same priority below
+        if rnd == 2:
+            idx = torch.randint(0, 5000, (n_items,), generator=g)    # crowded: few subtrees, many duplicates
+        pr = torch.rand(n_items, generator=g) * 3 + 0.05
+        uniq, inv = torch.unique(idx, return_inverse=True)
+        pr = pr[: uniq.numel()][inv]                                 # duplicates carry equal priorities
+        rp.update_priorities(idx, pr)
+        leaf[idx] = pr.double() ** cfg["priority_alpha"]
+        torch.cuda.synchronize()
+        torch.testing.assert_close(rp.leaf[:n].cpu().double(), leaf, rtol=1e-6, atol=1e-7)
+        got_s = [None if x is None else x.clone() for x in rp.sums]
+        got_m = [None if x is None else x.clone() for x in rp.mins]
+        rp.rebuild_tree()
+        for l in range(1, rp.L + 1):
+            torch.testing.assert_close(got_s[l], rp.sums[l], rtol=1e-12, atol=1e-9)
+            assert torch.equal(got_m[l], rp.mins[l])
+        assert abs(rp.total_priority() - leaf.sum().item()) < 1e-2 and int(rp._ticket.item()) == 0
+    assert abs(core.read_dev_state().max_priority - max(1.0, 3.05)) < 0.1
+
+
 def test_per_beta_anneals_with_step():
     cfg, core, rp = _mk(capacity=1000, per=True, B=64)
     rp.insert(_rows(rp, 500))
@@ -202,3 +236,54 @@ def test_update_from_replay_end_to_end(per, graph):
         rp.rebuild_tree()
         for l in range(1, rp.L + 1):
             torch.testing.assert_close(sums[l], rp.sums[l], rtol=1e-12, atol=1e-9)
+
+
+@pytest.mark.parametrize("zero_copy", [True, False])
+def test_ring_ingestor_moves_rows_ring_to_hbm(zero_copy):
+    """Explorer rings -> HBM replay: with ``zero_copy`` the DMA reads the rings' own (registered) shared memory and
+    slots return to the producer only after the copy's event; rows arrive complete and in order either way."""
+    import numpy as np
+    from d4pg_pytorch_amd.models.core import build_core
+    from d4pg_pytorch_amd.models.learner import RingIngestor
+    from d4pg_pytorch_amd.parallel.ipc import ShmRing
+    from d4pg_pytorch_amd.replay.hbm_replay import HbmReplay
+    cfg = default_config(env="BipedalWalker-v2", model="d4pg", batch_size=64, dense_size=64, device="cuda",
+                         replay_mem_size=8192, ingest_chunk=64)
+    core = build_core(cfg, "cuda")
+    rp = HbmReplay(cfg, "cuda", core.dev_state)
+    rings = [ShmRing.create(100, rp.row_ld) for _ in range(2)]       # small: the readable span wraps often
+    for r in rings:
+        r.set_check(True)
+    ing = RingIngestor(rings, rp, torch.device("cuda"), 64, zero_copy=zero_copy)
+    if zero_copy and not ing.zero_copy:
+        pytest.skip("the HIP runtime on this host refuses hipHostRegister (bench/exp/host_register_probe.py): "
+                    "the pinned-staging path is what runs here")
+    assert ing.zero_copy == zero_copy
+    rng = np.random.default_rng(0)
+    sent = [[], []]
+    got_total = 0
+    for it in range(60):
+        for k, r in enumerate(rings):
+            n = int(rng.integers(1, 70))
+            rows = rng.standard_normal((n, rp.row_ld)).astype(np.float32)
+            rows[:, 0] = k                                           # which ring
+            rows[:, 1] = np.arange(len(sent[k]), len(sent[k]) + n)   # running index inside the ring
+            ok = r.push(rows, timeout_ms=0)
+            sent[k].extend(rows[:ok])
+        got_total += ing.poll()
+        if it % 7 == 0:
+            torch.cuda.synchronize()
+    while sum(len(r) for r in rings):
+        got_total += ing.poll()
+        torch.cuda.synchronize()
+    ing.close() if zero_copy else None
+    torch.cuda.synchronize()
+    assert got_total == len(sent[0]) + len(sent[1]) == rp.size and got_total > 1500
+    assert all(len(r) == 0 and r.seq_errors == 0 for r in rings)
+    rows = rp.rows[: rp.size].cpu().numpy()
+    for k in range(2):
+        mine = rows[rows[:, 0] == k]
+        np.testing.assert_array_equal(mine[:, 1], np.arange(len(sent[k])))       # nothing lost, duplicated or reordered
+        np.testing.assert_array_equal(mine, np.stack(sent[k]))
+    for r in rings:
+        r.close()

@@ -1,0 +1,32 @@
+"""Seeded learning thresholds on the GPU: the fused HIP cores must actually solve the pendulum swing-up
+(in-process loop with device-resident explorers, ``utils/learning.py``; a random policy scores about -1200,
+a good one -150 .. -250).  The multi-seed comparison against the eager PyTorch core is
+``bench/learn_parity.py`` (table in ``profiles/learning/README.md``)."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("core", ["fp32", "bf16"])
+def test_d3pg_learns_the_pendulum(core):
+    from d4pg_pytorch_amd.utils.learning import train_pendulum_on_device
+    r = train_pendulum_on_device("d3pg", core, updates=10_000, seed=100, eval_every=1000)
+    assert r["initial_return"] < -1000
+    assert r["final_return"] > -400 and r["last5_mean_return"] > -450, r["curve"]
+
+
+def test_d4pg_fp32_learns_the_pendulum_within_20k_updates():
+    from d4pg_pytorch_amd.models.hip_core_f32 import HipCoreF32  # noqa: F401  (the default core)
+    from d4pg_pytorch_amd.utils.learning import train_pendulum_on_device
+    r = train_pendulum_on_device("d4pg", "fp32", updates=20_000, seed=103, eval_every=1000)
+    assert r["core_class"] == "HipCoreF32" and r["initial_return"] < -1000
+    assert r["best_return"] > -400 and r["final_return"] > -400, r["curve"]
+
+
+def test_same_seed_same_run():
+    """Everything in the loop is seeded and on the device (Philox streams for sampling, noise and resets):
+    two runs make the same curve."""
+    from d4pg_pytorch_amd.utils.learning import train_pendulum_on_device
+    a = train_pendulum_on_device("d3pg", "fp32", updates=1500, seed=5, eval_every=500)
+    b = train_pendulum_on_device("d3pg", "fp32", updates=1500, seed=5, eval_every=500)
+    assert a["curve"] == b["curve"]
