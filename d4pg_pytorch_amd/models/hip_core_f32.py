@@ -77,12 +77,14 @@ class HipCoreF32(HipCoreBf16):
         self.direct_ahead: Dict[str, int] = {}
         # Rows per workgroup.  A layer costs the time to stream its weights through one CU whatever the tile
         # height, until the MFMA work of the tile (2.3 us per 400 x 400 layer and 4 rows) exceeds it: 4-row
-        # tiles while their workgroups (critic + actor forward) fit the 256 CUs, taller tiles beyond.
+        # tiles while their workgroups (critic + actor forward) fit the 256 CUs, taller tiles beyond.  Measured
+        # (us per update, 4 / 8 / 16 rows): batch 512: 86 / 96 / -, 1024: 117 / 105 / -, 2048: 205 / 147 / 186,
+        # 4096 (Ant): 451 / 329 / 311  (bench/exp/ab_tile32.sh).
         want = str(cfg.get("phase_tile_rows", "auto"))
         if want in ("4", "8", "16"):
             self.mt = int(want) // 4
         else:
-            self.mt = 1 if B // 4 <= 128 else (2 if B // 8 <= 128 else 4)
+            self.mt = 1 if B // 4 <= 128 else (2 if B // 8 <= 256 else 4)
         while self.mt > 1 and B % (4 * self.mt):
             self.mt //= 2
         need = max(H.lib().d4pg_phase32_lds_bytes(self.dims, self.mt, 0),

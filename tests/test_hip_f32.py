@@ -33,7 +33,7 @@ CASES = [("d4pg", {}), ("d4pg", {"critic_loss": "ce", "dense_size": 128}), ("d3p
          ("d4pg", {"env": "Ant-v2", "batch_size": 128, "use_per_sample_gamma": False}),       # 4 input chunks
          ("ddpg", {"env": "Pendulum-v0", "dense_size": 100, "batch_size": 64}),
          ("d4pg", {"env": "Walker2d-v2", "batch_size": 1024, "dense_size": 256}),             # 8-row tiles
-         ("d4pg", {"env": "BipedalWalker-v2", "batch_size": 2048}),                           # 16-row tiles
+         ("d4pg", {"env": "BipedalWalker-v2", "batch_size": 2048, "phase_tile_rows": "16"}),  # 16-row tiles
          ("d4pg", {"batch_size": 36, "phase_tile_rows": "4"})]                                # batch not a multiple of 32
 
 
