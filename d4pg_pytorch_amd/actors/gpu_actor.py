@@ -89,7 +89,7 @@ class PackedActor32:
     @staticmethod
     def tile_rows(n: int) -> int:
         """Rows per workgroup / 4: 4-row tiles while their workgroups fit the chip (see models/hip_core_f32.py)."""
-        return 1 if n <= 1024 else (2 if n <= 4096 else 4)
+        return 1 if n <= 1024 else (2 if n <= 2048 else 4)
 
 
 class GpuActor:
