@@ -10,3 +10,9 @@ cat gpurun_out/rehearse/dp4.json
 unset D4PG_DIST_BACKEND
 timeout -k 10 300 python bench.py --dp-selftest --steps 1000 --warmup 100 > gpurun_out/rehearse/selftest.json 2> gpurun_out/rehearse/selftest.err
 cat gpurun_out/rehearse/selftest.json
+timeout -k 10 300 python bench.py --dp-selftest --steps 1000 --warmup 100 --dtype bf16 > gpurun_out/rehearse/selftest_bf16.json 2> gpurun_out/rehearse/selftest_bf16.err
+cat gpurun_out/rehearse/selftest_bf16.json
+timeout -k 10 300 python bench.py --dp-selftest --steps 640 --warmup 64 --env Ant-v2 --batch 4096 > gpurun_out/rehearse/selftest_ant4096.json 2> gpurun_out/rehearse/selftest_ant4096.err
+cat gpurun_out/rehearse/selftest_ant4096.json
+timeout -k 10 300 python bench.py --dp-selftest --steps 640 --warmup 64 --env Ant-v2 --batch 4096 --dtype bf16 > gpurun_out/rehearse/selftest_ant4096_bf16.json 2> gpurun_out/rehearse/selftest_ant4096_bf16.err
+cat gpurun_out/rehearse/selftest_ant4096_bf16.json
