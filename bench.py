@@ -200,6 +200,54 @@ def main() -> None:
     extra = {}
     dp_mode = "none"
     metrics_primary = None
+
+    def emit(core, dt, dp_mode, metrics_primary):
+        """Rank 0 prints the one JSON line of the run."""
+        metrics = metrics_primary if metrics_primary is not None else core.read_metrics()
+        finite = all(map(lambda v: v == v and abs(v) != float("inf"), (metrics["value_loss"], metrics["policy_loss"])))
+        if rank == 0:
+            sync_ups = args.steps / dt
+            value = sync_ups * world
+            out = {
+                "metric": "learner updates/sec",
+                "value": round(value, 2),
+                "unit": "batch-%d learner updates/s (sum over ranks)" % args.batch,
+                "n_gpus": world,
+                "steps": args.steps,
+                "warmup": args.warmup,
+                "repeats": repeats,
+                "ms_per_step": round(1000.0 * dt / args.steps, 5),
+                "higher_is_better": True,
+                "scaling": "weak",
+                "vs_baseline": None,
+                "dtype": args.dtype if not args.baseline else "fp32",
+                "data": "synthetic transitions (random-init weights, %d-row HBM replay prefilled with %d rows)"
+                        % (args.replay_size, min(args.prefill, args.replay_size)),
+                "sync_updates_per_sec": round(sync_ups, 2),
+                "transitions_per_sec": round(sync_ups * args.batch * world, 1),
+                "losses_finite": bool(finite),
+                "value_loss": metrics["value_loss"],
+                "policy_loss": metrics["policy_loss"],
+                "implementation": "eager-torch-unfused" if args.baseline else
+                                  (type(core).__name__ + ":" +
+                                   {"HipCoreF32": "hip-fused-rowlocal-fp32-mfma", "HipCoreBf16": "hip-fused-rowlocal-bf16",
+                                    "HipCore": "hip-per-layer-fp32-mfma"}.get(type(core).__name__, "?")
+                                   + ("" if args.no_graph else "+hipgraph")),
+                "config": {"model": "%s %s (S=%d, A=%d, H=400%s)" % (
+                               env, args.model.upper(), S, A, ", 51 atoms" if args.model == "d4pg" else ""),
+                           "global_batch": args.batch * world, "seq_len": 1,
+                           "n_step": 5, "replay": "per-hbm-sumtree" if args.per else "uniform-hbm",
+                           "parallelism": "dp%d" % world + {
+                               "none": "", "replicated": " (sharded HBM replay, all-gathered batches, replicated update)",
+                               "grad_allreduce": " (gradient all-reduce)"}[dp_mode]},
+            }
+            out.update(extra)
+            if "single_gpu_global_batch_value" in extra:
+                out["speedup_vs_single_gpu_global_batch"] = round(value / extra["single_gpu_global_batch_value"], 3)
+            if dp_mode == "grad_allreduce":
+                out["grad_allreduce_in_graph"] = bool(getattr(core, "_sync_in_graph", lambda: False)())
+            print(json.dumps(out), flush=True)
+
     if args.baseline:
         from d4pg_pytorch_amd.models.core import Batch, TorchCore
         core = TorchCore(cfg, device)
@@ -290,6 +338,20 @@ def main() -> None:
             extra[auto + "_value"] = round(args.steps / dt * world, 2)
             extra[auto + "_ms_per_step"] = round(1000.0 * dt / args.steps, 5)
             torch.cuda.empty_cache()
+            # The second mode must not cost the first its result: if it has not finished after a generous
+            # multiple of the first mode's time (a collective that never completes on this machine), every rank
+            # reports what it has and leaves.
+            import threading
+
+            def give_up():
+                extra[other + "_error"] = "timed out"
+                extra["dp_mode_selected"] = dp_mode + " (the other mode did not finish)"
+                if rank == 0:
+                    emit(core, dt, dp_mode, metrics_primary)
+                os._exit(0)
+            watchdog = threading.Timer(max(180.0, 40.0 * dt * (repeats + 1) + 120.0), give_up)
+            watchdog.daemon = True
+            watchdog.start()
             try:
                 core_o, dt_o = runners[other]()
                 extra[other + "_value"] = round(args.steps / dt_o * world, 2)
@@ -298,52 +360,11 @@ def main() -> None:
                     core, dt, dp_mode, metrics_primary = core_o, dt_o, other, core_o.read_metrics()
             except Exception as exc:
                 extra[other + "_error"] = repr(exc)[:200]
+            finally:
+                watchdog.cancel()
             extra["dp_mode_selected"] = dp_mode + " (faster of the two timed modes)"
 
-    metrics = metrics_primary if metrics_primary is not None else core.read_metrics()
-    finite = all(map(lambda v: v == v and abs(v) != float("inf"), (metrics["value_loss"], metrics["policy_loss"])))
-    if rank == 0:
-        sync_ups = args.steps / dt
-        value = sync_ups * world
-        out = {
-            "metric": "learner updates/sec",
-            "value": round(value, 2),
-            "unit": "batch-%d learner updates/s (sum over ranks)" % args.batch,
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "repeats": repeats,
-            "ms_per_step": round(1000.0 * dt / args.steps, 5),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": args.dtype if not args.baseline else "fp32",
-            "data": "synthetic transitions (random-init weights, %d-row HBM replay prefilled with %d rows)"
-                    % (args.replay_size, min(args.prefill, args.replay_size)),
-            "sync_updates_per_sec": round(sync_ups, 2),
-            "transitions_per_sec": round(sync_ups * args.batch * world, 1),
-            "losses_finite": bool(finite),
-            "value_loss": metrics["value_loss"],
-            "policy_loss": metrics["policy_loss"],
-            "implementation": "eager-torch-unfused" if args.baseline else
-                              (type(core).__name__ + ":" +
-                               {"HipCoreF32": "hip-fused-rowlocal-fp32-mfma", "HipCoreBf16": "hip-fused-rowlocal-bf16",
-                                "HipCore": "hip-per-layer-fp32-mfma"}.get(type(core).__name__, "?")
-                               + ("" if args.no_graph else "+hipgraph")),
-            "config": {"model": "%s %s (S=%d, A=%d, H=400%s)" % (
-                           env, args.model.upper(), S, A, ", 51 atoms" if args.model == "d4pg" else ""),
-                       "global_batch": args.batch * world, "seq_len": 1,
-                       "n_step": 5, "replay": "per-hbm-sumtree" if args.per else "uniform-hbm",
-                       "parallelism": "dp%d" % world + {
-                           "none": "", "replicated": " (sharded HBM replay, all-gathered batches, replicated update)",
-                           "grad_allreduce": " (gradient all-reduce)"}[dp_mode]},
-        }
-        out.update(extra)
-        if "single_gpu_global_batch_value" in extra:
-            out["speedup_vs_single_gpu_global_batch"] = round(value / extra["single_gpu_global_batch_value"], 3)
-        if dp_mode == "grad_allreduce":
-            out["grad_allreduce_in_graph"] = bool(getattr(core, "_sync_in_graph", lambda: False)())
-        print(json.dumps(out), flush=True)
+    emit(core, dt, dp_mode, metrics_primary)
     comm.close()
 
 

@@ -195,7 +195,15 @@ def _rccl_worker(rank, world, port, mode, dtype, out_dir):
 def test_rccl_two_gpus(mode, dtype, tmp_path):
     import torch.multiprocessing as mp
     port = 30500 + os.getpid() % 400
-    mp.start_processes(_rccl_worker, args=(2, port, mode, dtype, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    ctx = mp.start_processes(_rccl_worker, args=(2, port, mode, dtype, str(tmp_path)), nprocs=2, join=False,
+                             start_method="spawn")
+    import time
+    deadline = time.time() + 150.0          # a collective that never completes must fail the test, not hang the suite
+    while not ctx.join(timeout=5.0):
+        if time.time() > deadline:
+            for p in ctx.processes:
+                p.kill()
+            pytest.fail("two-rank RCCL run did not finish within 150 s")
     res = torch.load(tmp_path / "r0.pt", weights_only=True)
     if mode == "replicated":
         assert res["diff"] == 0.0
