@@ -61,6 +61,17 @@ D4PG_API int d4pg_reset_stamps32() {      // re-arm the running minima (slots 20
 #define STAMP_SPAN(k, i, is_end)
 #endif
 
+// The argument struct of a kernel, read in place from the kernel-argument segment.  A by-value struct parameter
+// is an addressable local object for the compiler; whether it manages to turn every access back into a scalar
+// load from the argument segment depends on the size of the kernel (variants of these kernels have ended up
+// copying all their arguments to scratch memory after small changes elsewhere, which also makes every buffer
+// descriptor built from them divergent).  Reading through the segment pointer leaves nothing to copy.  The
+// struct is the kernel's only parameter, so it sits at offset 0 of the segment.
+template <typename Args>
+__device__ __forceinline__ const Args& kernel_args() {
+    return *(const Args*)__builtin_amdgcn_kernarg_segment_ptr();      // (C-style cast: drops the address space)
+}
+
 constexpr int NW32 = 8;          // waves per phase workgroup: one unit (column tile or K-slice) each
 constexpr int LDS_PAD32 = 4;     // floats appended to every LDS row: the 4 rows of one wide read hit disjoint banks
 
@@ -90,7 +101,12 @@ struct Chain32 {
     }
     template <int SLOT>
     __device__ __forceinline__ void prefetch_n(const LayerW32& L) {
-        (SLOT == 0 ? t0 : t1) = fetch_first_rt(L, wave, lane);
+        (SLOT == 0 ? t0 : t1) = fetch_first_rt(L, L.kg, wave, lane);
+    }
+    // the same for a layer that may be skipped (`run` false: nothing is loaded, the registers stay dead)
+    template <int SLOT>
+    __device__ __forceinline__ void prefetch_n_if(const LayerW32& L, bool run) {
+        (SLOT == 0 ? t0 : t1) = fetch_first_rt(L, run ? L.kg : 0, wave, lane);
     }
     // K = hidden width, N = hidden width: KSH chunks per column tile
     template <int SLOT, typename F, typename P>
@@ -383,7 +399,8 @@ __device__ __forceinline__ void critic_tail(const CriticPhaseArgs32& a, Chain32<
 }
 
 template <int MT, int KSH, int KSN>
-__global__ __launch_bounds__(64 * NW32) void critic_phase32_kernel(const CriticPhaseArgs32 a) {
+__global__ __launch_bounds__(64 * NW32) void critic_phase32_kernel(const CriticPhaseArgs32) {
+    const CriticPhaseArgs32& a = kernel_args<CriticPhaseArgs32>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int M = 4 * MT;
     const PhaseDims& d = a.d;
@@ -522,14 +539,11 @@ __global__ __launch_bounds__(64 * NW32) void critic_phase32_kernel(const CriticP
     __syncthreads();
     STAMP(0, 6);
     // With the online critic's tiles made ahead its three layers are skipped; the first of them is
-    // prefetched by the layer before, so skipping is expressed as a layer without k-groups to load, with
-    // the field selected on its own (see csrc/fused.hip).
-    LayerW32 after_tc = a.cf[0];
-    after_tc.kg = ahead_ok ? 0 : a.cf[0].kg;
+    // prefetched by the layer before, so skipping is expressed as a prefetch without k-groups to load.
     ch.template split<1>(bufB, d.ldh, a.tc[2], [=](int r0, int col, f32x4 v) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) lg_t[(r0 + r) * nop + col] = v[r];
-    }, [&] { ch.template prefetch_n<0>(after_tc); });
+    }, [&] { ch.template prefetch_n_if<0>(a.cf[0], !ahead_ok); });
     if (!ahead_ok) {
         // ---- online critic: (s, a) -> logits, activations stashed for wgrad ----
         ch.template narrow<0>(xin, d.ldx, a.cf[0], [=](int r0, int col, f32x4 v) {
@@ -612,7 +626,8 @@ __device__ __forceinline__ void critic_ahead_role(const ActorPhaseArgs32& a, int
 }
 
 template <int MT, int KSH, int KSN>
-__global__ __launch_bounds__(64 * NW32) void actor_phase32_kernel(const ActorPhaseArgs32 a) {
+__global__ __launch_bounds__(64 * NW32) void actor_phase32_kernel(const ActorPhaseArgs32) {
+    const ActorPhaseArgs32& a = kernel_args<ActorPhaseArgs32>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int M = 4 * MT;
     const PhaseDims& d = a.d;
@@ -756,7 +771,8 @@ struct ActorInferArgs32 {
 };
 
 template <int MT, int KSH, int KSN>
-__global__ __launch_bounds__(64 * NW32) void actor_infer32_kernel(const ActorInferArgs32 a) {
+__global__ __launch_bounds__(64 * NW32) void actor_infer32_kernel(const ActorInferArgs32) {
+    const ActorInferArgs32& a = kernel_args<ActorInferArgs32>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int M = 4 * MT;
     const int row0 = blockIdx.x * M;

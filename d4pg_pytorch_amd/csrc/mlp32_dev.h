@@ -98,9 +98,11 @@ __device__ __forceinline__ Chunk32 load_chunk(const WSrc32& s, int chunk) {
     return c;
 }
 
-// A wave-load costs the CU's load path 16 cycles whether its lanes are in range or not (a 400 x 400 layer
-// is 7 x 104 of them = 5.3 us, and that, not HBM or L2 bandwidth, is what a layer costs), so loads that
-// would only fetch padding are not issued: see the run-time variants below.
+// What a layer costs is the bytes its CU pulls through the vector cache (64 B / clk: 640 KB of a 400 x 400
+// layer = 4.2 us, 5.3 us measured), so k-padding (real zeros in memory) is not loaded: see the run-time
+// variants below.  Lanes that are out of range return zeros without a fetch and cost nothing measurable:
+// storing the 16-column last tile of a 400-wide layer so that its wave issues a quarter of the loads
+// (bench/exp/notes/rem16_tile_experiment.patch) left the update time unchanged (77.4 vs 77.1 us).
 
 // The first min(PF32, NCH) chunks of the wave's unit, unconditionally (a wave without a unit reads zeros
 // from out-of-range offsets): the consumer's load counting stays exact.
@@ -126,12 +128,13 @@ __device__ __forceinline__ void load_groups(Chunk32& c, const WSrc32& s, int chu
                                                                                     s.soff + chunk * CHUNK_BYTES + g * 1024, 0));
     __builtin_amdgcn_sched_barrier(0);
 }
-__device__ __forceinline__ Pre32 fetch_first_rt(const LayerW32& L, int wave, int lane) {
+// (kg_of_layer: L.kg, or 0 for a layer that is not going to run: nothing is loaded then)
+__device__ __forceinline__ Pre32 fetch_first_rt(const LayerW32& L, int kg_of_layer, int wave, int lane) {
     Pre32 t;
     const int col = wave * 64 + lane;
     t.bias = L.bias[col < L.N ? col : 0];
     const WSrc32 src = wsrc_of(L, wave, lane);
-    const int kg = wave < L.ntiles ? L.kg : 0;
+    const int kg = wave < L.ntiles ? kg_of_layer : 0;
 #pragma unroll
     for (int j = 0; j < PF32; ++j) load_groups(t.c[j], src, j, kg);
     return t;
