@@ -34,7 +34,7 @@ Data-parallel modes (``--dp-mode``, N > 1):
                   the two all-reduces are nodes of the update's graph (32 updates per replay).
   both (default)  times the two back to back; ``value`` is the faster one (``dp_mode_selected``), both are reported
                   (``replicated_value``, ``grad_allreduce_value``) together with what the framework's static rule
-                  picks (``dp_mode_auto``: replicated up to a global batch of 8192 rows; gradient all-reduce beyond).
+                  picks (``dp_mode_auto``: replicated up to a global batch of 2048 rows in fp32, 8192 in bf16; gradient all-reduce beyond).
 Both make the update a single learner would make on the concatenated global batch.
 For N > 1 every rank also times two single-GPU runs without collectives on its own GPU:
 ``single_gpu_same_config_value`` (the per-rank configuration, batch 256: what the N-GPU ``value``
@@ -328,7 +328,7 @@ def main() -> None:
             # both modes are timed, the one the framework's static rule (dp_mode: auto) would pick first so that
             # nothing the other run does can affect it; `value` is the faster of the two (a job is free to set
             # dp_mode), both are reported with the rule's own pick (`dp_mode_auto`)
-            auto = resolve_dp_mode("auto", args.batch, world)
+            auto = resolve_dp_mode("auto", args.batch, world, args.dtype)
             runners = {"replicated": run_replicated, "grad_allreduce": run_grad_allreduce}
             other = "grad_allreduce" if auto == "replicated" else "replicated"
             core, dt = runners[auto]()

@@ -86,7 +86,7 @@ EXTENSION_DEFAULTS: Dict[str, Any] = {
     "learner_devices": None,         # list of device indices; default range(num_learners)
     "dp_mode": "auto",               # num_learners > 1: "replicated" (all-gather the sampled rows, every rank runs the
                                      # update on the global batch) | "grad_allreduce" (all-reduce both gradient buckets)
-                                     # | "auto": replicated up to a global batch of 8192 rows, else grad_allreduce
+                                     # | "auto": replicated up to a global batch of 2048 rows in fp32 (8192 in bf16), else grad_allreduce
     "exploiter_device": None,        # default: same as ``device``
     "envs_per_agent": 1,             # vectorised environments per explorer/exploiter process
     "gpu_rollout_envs": 0,           # > 0: that many explorer environments stepped ON the learner's GPU (policy, noise,

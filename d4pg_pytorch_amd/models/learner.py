@@ -259,7 +259,8 @@ class Learner:
         self.log_dir = log_dir
         self.num_train_steps = int(config["num_steps_train"])
         # replicated data parallelism: every rank runs the update on the global batch
-        dp_mode = resolve_dp_mode(config.get("dp_mode", "auto"), int(config["batch_size"]), self.comm.world)
+        dp_mode = resolve_dp_mode(config.get("dp_mode", "auto"), int(config["batch_size"]), self.comm.world,
+                                  str(config.get("compute_dtype", "auto")))
         self.replicated = (self.comm.world > 1 and dp_mode == "replicated"
                            and self.device.type == "cuda" and config.get("fused_learner", "auto") != "torch")
         core_cfg = dict(config, batch_size=int(config["batch_size"]) * self.comm.world) if self.replicated else config

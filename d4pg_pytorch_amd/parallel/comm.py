@@ -176,19 +176,22 @@ class TorchDistComm(Comm):
             self._owns = False
 
 
-#: Largest global batch for which ``dp_mode: auto`` replicates the update.  Measured on one MI355X, us per
-#: update: replicated, by global batch: 256: 55, 2048: 66, 4096: 92, 8192: 131; the gradient-exchange
-#: path (three graph segments, two all-reduces, separate optimiser kernels, per-update sampling kernel)
-#: over a world of one, by local batch: 256: 110, 4096: 161 - before any xGMI latency of the two
-#: 0.7-0.9 MB all-reduces.  Redoing the other ranks' rows is cheaper than that up to 8192 rows.
-REPLICATED_MAX_GLOBAL_BATCH = 8192
+#: Largest global batch for which ``dp_mode: auto`` replicates the update, by compute precision.  Measured on
+#: one MI355X, us per update on the global batch (what every rank of the replicated mode pays, plus the
+#: all-gather): fp32 256: 78, 512: 86, 1024: 105, 2048: 143, 4096: 258; bf16 256: 52, 2048: 64, 4096: 89, 8192: 131.
+#: The gradient-exchange mode over a world of ONE (two all-reduces as nodes of the update graph, stand-alone
+#: optimiser kernels) costs 94 us (fp32) / 68 us (bf16) at 256 rows per rank before any xGMI latency of the two
+#: 0.7-0.9 MB all-reduces, i.e. an estimated 150-170 / 125-145 us on eight GPUs: redoing the other ranks' rows
+#: is cheaper than that up to 2048 (fp32) / 8192 (bf16) rows.
+REPLICATED_MAX_GLOBAL_BATCH = {"fp32": 2048, "bf16": 8192}
 
 
-def resolve_dp_mode(mode: str, local_batch: int, world: int) -> str:
+def resolve_dp_mode(mode: str, local_batch: int, world: int, compute_dtype: str = "fp32") -> str:
     """``auto`` -> ``replicated`` while the global batch is small enough, else ``grad_allreduce``."""
     if mode != "auto":
         return mode
-    return "replicated" if int(local_batch) * int(world) <= REPLICATED_MAX_GLOBAL_BATCH else "grad_allreduce"
+    limit = REPLICATED_MAX_GLOBAL_BATCH["bf16" if compute_dtype == "bf16" else "fp32"]
+    return "replicated" if int(local_batch) * int(world) <= limit else "grad_allreduce"
 
 
 def attach_data_parallel(core, comm: Comm) -> None:

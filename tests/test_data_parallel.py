@@ -106,9 +106,11 @@ def test_dp_mode_auto_replicates_only_small_global_batches():
     from d4pg_pytorch_amd.config import default_config
     from d4pg_pytorch_amd.parallel.comm import REPLICATED_MAX_GLOBAL_BATCH, resolve_dp_mode
     assert default_config(env="Pendulum-v0")["dp_mode"] == "auto"
-    assert REPLICATED_MAX_GLOBAL_BATCH == 8192
+    assert REPLICATED_MAX_GLOBAL_BATCH == {"fp32": 2048, "bf16": 8192}
     assert resolve_dp_mode("auto", 256, 8) == "replicated"
-    assert resolve_dp_mode("auto", 1024, 8) == "replicated"
+    assert resolve_dp_mode("auto", 1024, 8) == "grad_allreduce"            # fp32 (the default): 8192 rows are too many
+    assert resolve_dp_mode("auto", 1024, 8, "bf16") == "replicated"
+    assert resolve_dp_mode("auto", 4096, 8, "bf16") == "grad_allreduce"
     assert resolve_dp_mode("auto", 4096, 8) == "grad_allreduce"
     assert resolve_dp_mode("auto", 16384, 1) == "grad_allreduce"     # irrelevant for one rank, but well defined
     assert resolve_dp_mode("grad_allreduce", 256, 2) == "grad_allreduce"
