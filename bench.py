@@ -19,7 +19,8 @@ Other shapes: --env Ant-v2 --batch 4096 --model d3pg --per ...
 
 Precision: the headline (``value``, ``dtype: fp32``) is the reference's own precision — every product an exact
 f32 multiply-add on the matrix cores.  For N == 1 the same run also times the bf16-operand pipeline and
-reports it as ``bf16_value`` / ``bf16_ms_per_step``.  A request of fewer than 256 steps is timed as 15
+reports it as ``bf16_value`` / ``bf16_ms_per_step``, and the reference's op sequence in eager PyTorch-ROCm as
+``eager_torch_value`` (``speedup_vs_eager_torch``; ``--no-bf16`` skips both).  A request of fewer than 256 steps is timed as 15
 regions of exactly that many updates each (``repeats``), and the median region is reported.
 
 Data-parallel modes (``--dp-mode``, N > 1):
@@ -321,6 +322,32 @@ def main() -> None:
                 except Exception as exc:
                     extra["bf16_error"] = repr(exc)[:200]
                 cfg = cfg_main
+                # ... and the reference's op sequence in eager PyTorch on this GPU (the reference publishes no
+                # numbers: this is the same-hardware yardstick).  At most 200 updates, it is ~30x slower.
+                try:
+                    from d4pg_pytorch_amd.models.core import Batch, TorchCore
+                    tcore = TorchCore(cfg, device)
+                    trows = synthetic_rows(min(args.prefill, 50_000), S, A, 2 * S + A + 3, gamma_n, device, seed=7)
+
+                    def eager_step():
+                        idx = torch.randint(0, trows.shape[0], (args.batch,), device=device)
+                        r = trows[idx]
+                        tcore.update(Batch(r[:, :S], r[:, S:S + A], r[:, S + A], r[:, S + A + 3:S + A + 3 + S],
+                                           r[:, S + A + 1], r[:, S + A + 2], None, idx))
+                    n_e = max(20, min(200, args.steps))
+                    for _ in range(10):
+                        eager_step()
+                    torch.cuda.synchronize(device)
+                    t0 = time.perf_counter()
+                    for _ in range(n_e):
+                        eager_step()
+                    torch.cuda.synchronize(device)
+                    dt_e = (time.perf_counter() - t0) / n_e
+                    extra["eager_torch_value"] = round(1.0 / dt_e, 2)
+                    extra["eager_torch_ms_per_step"] = round(1000.0 * dt_e, 5)
+                    extra["speedup_vs_eager_torch"] = round(dt_e / (dt / args.steps), 2)
+                except Exception as exc:
+                    extra["eager_torch_error"] = repr(exc)[:200]
         elif args.dp_mode != "both":
             dp_mode = args.dp_mode
             core, dt = run_replicated() if dp_mode == "replicated" else run_grad_allreduce()
