@@ -35,17 +35,20 @@ def gpu_rollout_bench(args):
     from d4pg_pytorch_amd.actors.gpu_actor import GpuActor
     from d4pg_pytorch_amd.actors.gpu_rollout import DeviceRollout
     from d4pg_pytorch_amd.config import default_config
-    from d4pg_pytorch_amd.envs.device_pendulum import DevicePendulum
+    from d4pg_pytorch_amd.envs.device_envs import make_device_env
     from d4pg_pytorch_amd.models.core import build_core
     from d4pg_pytorch_amd.replay.hbm_replay import HbmReplay
     E, T = args.envs, args.segment
-    cfg = default_config(env="Pendulum-v0", model="d4pg", batch_size=256, dense_size=400, device="cuda",
-                         n_step_returns=5, replay_mem_size=1_000_000, v_min=-20.0, v_max=0.0,
-                         replay_memory_prioritized=args.per)
+    pend = args.rollout_env.startswith("Pendulum")
+    cfg = default_config(env=args.rollout_env, model="d4pg", batch_size=256, dense_size=400, device="cuda",
+                         n_step_returns=5, replay_mem_size=1_000_000, v_min=-20.0 if pend else -100.0,
+                         v_max=0.0 if pend else 100.0, replay_memory_prioritized=args.per,
+                         synthetic_env=not pend and args.rollout_env != "InvertedPendulum-v2")
     core = build_core(cfg, "cuda")
     rp = HbmReplay(cfg, "cuda", core.dev_state)
     core.attach_replay(rp)
-    ro = DeviceRollout(cfg, DevicePendulum(E, "cuda", seed=1), rp, "cuda", segment=T, seed=1)
+    ro = DeviceRollout(cfg, make_device_env(cfg, E, "cuda", seed=1), rp, "cuda", segment=T, seed=1)
+    S_, A_ = cfg["state_dim"], cfg["action_dim"]
     flat, base = core.online.flat.data_ptr(), core.layout.actor.base
 
     def sync_time(fn, n):
@@ -77,9 +80,9 @@ def gpu_rollout_bench(args):
     # ---- one act() of a GPU agent ----
     act_us = {}
     for n in (1, 64):
-        ga = GpuActor(3, 1, 400, max_batch=n)
+        ga = GpuActor(S_, A_, 400, max_batch=n)
         ga.load_flat(core.online.actor_flat().detach().cpu().numpy())
-        x = np.zeros((n, 3), np.float32)
+        x = np.zeros((n, S_), np.float32)
         for _ in range(20):
             ga.act(x)
         t0 = time.perf_counter()
@@ -89,7 +92,7 @@ def gpu_rollout_bench(args):
         launches = ga.launches_per_act
     mean_ret, n_ep = ro.episode_stats()
     steps = args.segments * T * E
-    out = {"mode": "gpu_rollout", "env": "Pendulum-v0 (device kernels)", "envs": E, "segment_steps": T,
+    out = {"mode": "gpu_rollout", "env": "%s (device kernels: %s)" % (args.rollout_env, type(ro.env).__name__), "envs": E, "segment_steps": T,
            "segments": args.segments, "replay": ("per-" if args.per else "uniform-") + "hbm", "dense_size": 400,
            "env_steps_per_s_rollout_alone": round(steps / alone, 0),
            "us_per_env_step_all_envs": round(alone / (args.segments * T) * 1e6, 2),
@@ -107,6 +110,8 @@ def main():
     ap.add_argument("--config")
     ap.add_argument("--gpu-rollout", action="store_true")
     ap.add_argument("--envs", type=int, default=4096)
+    ap.add_argument("--rollout-env", default="Pendulum-v0",
+                    help="--gpu-rollout: Pendulum-v0, InvertedPendulum-v2 (cart-pole) or any known id (shape-only dynamics)")
     ap.add_argument("--segment", type=int, default=32)
     ap.add_argument("--segments", type=int, default=200)
     ap.add_argument("--per", type=int, default=0)

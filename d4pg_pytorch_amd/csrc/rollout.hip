@@ -129,6 +129,198 @@ D4PG_API int d4pg_pendulum_step(const PendulumArgs* a, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Continuous-force cart-pole balancing (envs/synthetic.py::CartPoleContinuousVec, the stand-in with the shape of
+// InvertedPendulum-v2): +1 per step, TERMINAL when the pole or the cart leaves its range, time limit on top.
+struct CartPoleArgs {
+    float* state;            // [E][4] x, x_dot, theta, theta_dot, updated in place
+    int* t;                  // [E]
+    float* ep_return;        // [E]
+    const float* action;     // [E][ld_act] force in column 0, clipped to [-1, 1]
+    float* obs;              // [E][4] what the policy sees next (a fresh state where an episode ended)
+    float* next_obs;         // [E][4] the state that followed the action
+    float* reward;           // [E]
+    float* done;             // [E] 1: fell (and the time limit, with limit_terminal)
+    float* trunc;            // [E] 1: time limit without limit_terminal
+    float* noise;            // [E][ld_act] exploration-noise state, zeroed where an episode ends; or null
+    double* stats;           // [2] sum of finished episode returns, number of finished episodes
+    unsigned long long* counter;
+    unsigned long long seed;
+    int E, ld_act, time_limit, init;
+    int limit_terminal;
+    int pad_;
+};
+__global__ __launch_bounds__(256) void cartpole_step_kernel(const CartPoleArgs a) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long ctr = *a.counter;
+    if (e >= a.E) return;
+    const float gravity = 9.8f, masscart = 1.f, masspole = 0.1f, length = 0.5f, force_mag = 10.f, tau = 0.02f;
+    float x = a.state[e * 4 + 0], xd = a.state[e * 4 + 1], th = a.state[e * 4 + 2], thd = a.state[e * 4 + 3];
+    int t = a.t[e];
+    bool reset = a.init != 0;
+    if (!a.init) {
+        const float force = fminf(1.f, fmaxf(-1.f, a.action[(size_t)e * a.ld_act])) * force_mag;
+        const float total = masscart + masspole, pml = masspole * length;
+        const float c = cosf(th), sn = sinf(th);
+        const float temp = (force + pml * thd * thd * sn) / total;
+        const float th_acc = (gravity * sn - c * temp) / (length * (4.f / 3.f - masspole * c * c / total));
+        const float x_acc = temp - pml * th_acc * c / total;
+        x += tau * xd;
+        xd += tau * x_acc;
+        th += tau * thd;
+        thd += tau * th_acc;
+        t += 1;
+        a.next_obs[e * 4 + 0] = x;
+        a.next_obs[e * 4 + 1] = xd;
+        a.next_obs[e * 4 + 2] = th;
+        a.next_obs[e * 4 + 3] = thd;
+        a.reward[e] = 1.f;
+        const bool fell = fabsf(th) > 0.2f || fabsf(x) > 2.4f;
+        const bool limit = a.time_limit > 0 && t >= a.time_limit;
+        a.done[e] = (fell || (limit && a.limit_terminal)) ? 1.f : 0.f;
+        a.trunc[e] = (limit && !fell && !a.limit_terminal) ? 1.f : 0.f;
+        const float ret = a.ep_return[e] + 1.f;
+        reset = fell || limit;
+        if (reset) {
+            atomicAdd(&a.stats[0], (double)ret);
+            atomicAdd(&a.stats[1], 1.0);
+        }
+        a.ep_return[e] = reset ? 0.f : ret;
+    }
+    if (reset) {
+        uint32_t r[4];
+        philox4x32((uint32_t)e, (uint32_t)ctr, (uint32_t)(ctr >> 32), 0xC0FFEEu, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), r);
+        x = ((float)(r[0] >> 8) * (1.0f / 16777216.0f) - 0.5f) * 0.1f;
+        xd = ((float)(r[1] >> 8) * (1.0f / 16777216.0f) - 0.5f) * 0.1f;
+        th = ((float)(r[2] >> 8) * (1.0f / 16777216.0f) - 0.5f) * 0.1f;
+        thd = ((float)(r[3] >> 8) * (1.0f / 16777216.0f) - 0.5f) * 0.1f;
+        t = 0;
+        if (a.init) a.ep_return[e] = 0.f;
+        if (a.noise != nullptr)
+            for (int j = 0; j < a.ld_act; ++j) a.noise[(size_t)e * a.ld_act + j] = 0.f;
+    }
+    a.state[e * 4 + 0] = x;
+    a.state[e * 4 + 1] = xd;
+    a.state[e * 4 + 2] = th;
+    a.state[e * 4 + 3] = thd;
+    a.t[e] = t;
+    a.obs[e * 4 + 0] = x;
+    a.obs[e * 4 + 1] = xd;
+    a.obs[e * 4 + 2] = th;
+    a.obs[e * 4 + 3] = thd;
+}
+D4PG_API int d4pg_cartpole_step(const CartPoleArgs* a, hipStream_t stream) {
+    if (a->E < 1 || a->state == nullptr || a->t == nullptr || a->obs == nullptr || a->counter == nullptr) return -1;
+    if (!a->init && (a->action == nullptr || a->next_obs == nullptr || a->reward == nullptr || a->done == nullptr ||
+                     a->trunc == nullptr || a->stats == nullptr || a->ld_act < 1))
+        return -2;
+    hipLaunchKernelGGL(cartpole_step_kernel, dim3((a->E + 255) / 256), dim3(256), 0, stream, *a);
+    hipLaunchKernelGGL(rollout_counter_kernel, dim3(1), dim3(64), 0, stream, a->counter);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Shape-only environment of any observation / action size (envs/synthetic.py::SyntheticVec): a fixed random
+// contraction s' = tanh(s M + a N + noise), reward -mean(s'^2) - 0.01 |a|^2, episodes end by time limit or with a
+// small probability per step.  Two kernels per step: the new states (one thread per state component, reading
+// the old state of its environment), then bookkeeping per environment.
+struct SyntheticEnvArgs {
+    float* state;            // [E][S]
+    int* t;
+    float* ep_return;
+    const float* M;          // [S][S]
+    const float* N;          // [A][S]
+    const float* action;     // [E][ld_act]
+    float* obs;              // [E][S]
+    float* next_obs;         // [E][S]
+    float* reward;
+    float* done;
+    float* trunc;
+    float* noise;
+    double* stats;
+    unsigned long long* counter;
+    unsigned long long seed;
+    int E, S, A, ld_act, time_limit, init;
+    float terminal_prob, noise_std;
+};
+__device__ __forceinline__ float philox_normal(uint32_t a, uint32_t b, unsigned long long ctr, uint32_t stream,
+                                               unsigned long long seed) {
+    uint32_t r[4];
+    philox4x32(a, b ^ (uint32_t)(ctr << 8), (uint32_t)(ctr >> 24), stream, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    const float u1 = fmaxf((float)(r[0] >> 8) * (1.0f / 16777216.0f), 1e-7f);
+    const float u2 = (float)(r[1] >> 8) * (1.0f / 16777216.0f);
+    return sqrtf(-2.f * logf(u1)) * cosf(6.2831853f * u2);
+}
+__global__ __launch_bounds__(256) void synthetic_next_kernel(const SyntheticEnvArgs a) {
+    const unsigned long long ctr = *a.counter;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)a.E * a.S) return;
+    const int e = (int)(i / a.S), j = (int)(i - (long long)e * a.S);
+    float acc = a.noise_std * philox_normal((uint32_t)e, (uint32_t)j, ctr, 0x51u, a.seed);
+    const float* s = a.state + (size_t)e * a.S;
+    for (int k = 0; k < a.S; ++k) acc += s[k] * a.M[(size_t)k * a.S + j];
+    const float* u = a.action + (size_t)e * a.ld_act;
+    for (int k = 0; k < a.A; ++k) acc += u[k] * a.N[(size_t)k * a.S + j];
+    a.next_obs[i] = tanhf(acc);
+}
+__global__ __launch_bounds__(256) void synthetic_book_kernel(const SyntheticEnvArgs a) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long ctr = *a.counter;
+    if (e >= a.E) return;
+    float* s = a.state + (size_t)e * a.S;
+    int t = a.t[e];
+    bool reset = a.init != 0;
+    if (!a.init) {
+        const float* ns = a.next_obs + (size_t)e * a.S;
+        float sq = 0.f, ua = 0.f;
+        for (int k = 0; k < a.S; ++k) {
+            s[k] = ns[k];
+            sq += ns[k] * ns[k];
+        }
+        for (int k = 0; k < a.A; ++k) ua += a.action[(size_t)e * a.ld_act + k] * a.action[(size_t)e * a.ld_act + k];
+        const float rew = -sq / (float)a.S - 0.01f * ua;
+        t += 1;
+        uint32_t r[4];
+        philox4x32((uint32_t)e, (uint32_t)ctr, (uint32_t)(ctr >> 32), 0x7E2Du, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), r);
+        const bool term = (float)(r[0] >> 8) * (1.0f / 16777216.0f) < a.terminal_prob;
+        const bool limit = a.time_limit > 0 && t >= a.time_limit;
+        a.reward[e] = rew;
+        a.done[e] = (term || limit) ? 1.f : 0.f;          // like the host class: both read as done
+        a.trunc[e] = 0.f;
+        const float ret = a.ep_return[e] + rew;
+        reset = term || limit;
+        if (reset) {
+            atomicAdd(&a.stats[0], (double)ret);
+            atomicAdd(&a.stats[1], 1.0);
+        }
+        a.ep_return[e] = reset ? 0.f : ret;
+    }
+    if (reset) {
+        for (int k = 0; k < a.S; ++k) s[k] = 0.5f * philox_normal((uint32_t)e, (uint32_t)k, ctr, 0xA5u, a.seed);
+        t = 0;
+        if (a.init) a.ep_return[e] = 0.f;
+        if (a.noise != nullptr)
+            for (int j = 0; j < a.ld_act; ++j) a.noise[(size_t)e * a.ld_act + j] = 0.f;
+    }
+    a.t[e] = t;
+    for (int k = 0; k < a.S; ++k) a.obs[(size_t)e * a.S + k] = s[k];
+}
+D4PG_API int d4pg_synthetic_env_step(const SyntheticEnvArgs* a, hipStream_t stream) {
+    if (a->E < 1 || a->S < 1 || a->A < 1 || a->state == nullptr || a->t == nullptr || a->obs == nullptr ||
+        a->counter == nullptr || a->ep_return == nullptr)
+        return -1;
+    if (!a->init) {
+        if (a->action == nullptr || a->next_obs == nullptr || a->reward == nullptr || a->done == nullptr ||
+            a->trunc == nullptr || a->stats == nullptr || a->M == nullptr || a->N == nullptr || a->ld_act < a->A)
+            return -2;
+        const long long n = (long long)a->E * a->S;
+        hipLaunchKernelGGL(synthetic_next_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, *a);
+    }
+    hipLaunchKernelGGL(synthetic_book_kernel, dim3((a->E + 255) / 256), dim3(256), 0, stream, *a);
+    hipLaunchKernelGGL(rollout_counter_kernel, dim3(1), dim3(64), 0, stream, a->counter);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
 struct RolloutRowsArgs {
     const float* obs;        // [T][E][S]   observation the action was chosen from
     const float* act;        // [T][E][ld_act]
@@ -210,3 +402,5 @@ D4PG_SIZEOF(PackMat32)
 D4PG_SIZEOF(PackActorArgs32)
 D4PG_SIZEOF(PendulumArgs)
 D4PG_SIZEOF(RolloutRowsArgs)
+D4PG_SIZEOF(CartPoleArgs)
+D4PG_SIZEOF(SyntheticEnvArgs)

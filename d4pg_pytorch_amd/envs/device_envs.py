@@ -1,0 +1,125 @@
+"""More environments resident on the GPU, next to ``envs/device_pendulum.py`` (same interface: ``reset``,
+``step``, ``episode_stats``, fields ``E``, ``state_dim``, ``action_dim``, ``time_limit``, ``noise``).
+
+* :class:`DeviceCartPole` — ``envs/synthetic.py::CartPoleContinuousVec`` (the stand-in with the shape of
+  ``InvertedPendulum-v2``) as one kernel per step: an environment with TERMINAL states, so the device-side
+  n-step assembly sees ``done`` flags that stop the bootstrap, not only time limits.
+* :class:`DeviceSynthetic` — ``envs/synthetic.py::SyntheticVec`` for any observation / action shape (the same
+  fixed dynamics matrices), so that the throughput configurations (Ant: 111 / 8, ...) can run their explorers
+  on the GPU as well.
+
+:func:`make_device_env` picks the one that stands for ``config['env']``.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from ..ops import hip as H
+from .device_pendulum import DevicePendulum
+
+
+class _DeviceEnvBase:
+    reward_scale = 1.0
+
+    def __init__(self, num_envs: int, state_dim: int, action_dim: int, device, seed: int, time_limit: int):
+        H.lib()
+        self.E, self.state_dim, self.action_dim = int(num_envs), int(state_dim), int(action_dim)
+        self.device, self.time_limit = torch.device(device), int(time_limit)
+        z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=self.device)   # noqa: E731
+        self.state, self.ep_return = z(self.E, self.state_dim), z(self.E)
+        self.t = z(self.E, dt=torch.int32)
+        self.stats = z(2, dt=torch.float64)
+        self.counter = z(1, dt=torch.int64)
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.noise: Optional[torch.Tensor] = None
+        self._seen = (0.0, 0)
+
+    def _fill(self, a, init: int) -> None:
+        a.state, a.t, a.ep_return = self.state.data_ptr(), self.t.data_ptr(), self.ep_return.data_ptr()
+        a.stats, a.counter, a.seed = self.stats.data_ptr(), self.counter.data_ptr(), self.seed
+        a.E, a.time_limit, a.init = self.E, self.time_limit, init
+        if self.noise is not None:
+            a.noise, a.ld_act = self.noise.data_ptr(), self.noise.shape[1]
+
+    def _launch(self, a) -> None:
+        raise NotImplementedError
+
+    def _args(self, init: int):
+        raise NotImplementedError
+
+    def reset(self, obs_out: torch.Tensor) -> torch.Tensor:
+        a = self._args(1)
+        a.obs = obs_out.data_ptr()
+        self._launch(a)
+        return obs_out
+
+    def step(self, action: torch.Tensor, obs_out: torch.Tensor, next_obs_out: torch.Tensor, reward_out: torch.Tensor,
+             done_out: torch.Tensor, trunc_out: torch.Tensor) -> None:
+        a = self._args(0)
+        a.action, a.ld_act = action.data_ptr(), action.shape[1]
+        a.obs, a.next_obs = obs_out.data_ptr(), next_obs_out.data_ptr()
+        a.reward, a.done, a.trunc = reward_out.data_ptr(), done_out.data_ptr(), trunc_out.data_ptr()
+        self._launch(a)
+
+    def episode_stats(self) -> Tuple[Optional[float], int]:
+        s = self.stats.cpu()
+        total, count = float(s[0].item()), int(s[1].item())
+        d_total, d_count = total - self._seen[0], count - self._seen[1]
+        self._seen = (total, count)
+        return (d_total / d_count if d_count else None), d_count
+
+
+class DeviceCartPole(_DeviceEnvBase):
+    def __init__(self, num_envs: int, device="cuda", seed: int = 0, time_limit: int = 1000, limit_terminal: bool = True):
+        super().__init__(num_envs, 4, 1, device, seed, time_limit)
+        self.limit_terminal = bool(limit_terminal)      # the host class reports its time limit as done
+
+    def _args(self, init: int) -> H.CartPoleArgs:
+        a = H.CartPoleArgs()
+        self._fill(a, init)
+        a.limit_terminal = int(self.limit_terminal)
+        return a
+
+    def _launch(self, a) -> None:
+        H.launch("d4pg_cartpole_step", a)
+
+
+class DeviceSynthetic(_DeviceEnvBase):
+    def __init__(self, env_name: str, num_envs: int, state_dim: int, action_dim: int, device="cuda", seed: int = 0,
+                 time_limit: int = 1000, terminal_prob: float = 0.001, noise_std: float = 0.05):
+        super().__init__(num_envs, state_dim, action_dim, device, seed, time_limit)
+        from .synthetic import SyntheticVec
+        host = SyntheticVec(env_name, 1, state_dim, action_dim)          # the same dynamics matrices as on the host
+        self.M = torch.from_numpy(np.ascontiguousarray(host.M)).to(self.device)
+        self.N = torch.from_numpy(np.ascontiguousarray(host.N)).to(self.device)
+        self.terminal_prob, self.noise_std = float(terminal_prob), float(noise_std)
+
+    def _args(self, init: int) -> H.SyntheticEnvArgs:
+        a = H.SyntheticEnvArgs()
+        self._fill(a, init)
+        a.M, a.N, a.S, a.A = self.M.data_ptr(), self.N.data_ptr(), self.state_dim, self.action_dim
+        a.terminal_prob, a.noise_std = self.terminal_prob, self.noise_std
+        return a
+
+    def _launch(self, a) -> None:
+        H.launch("d4pg_synthetic_env_step", a)
+
+
+def make_device_env(cfg, num_envs: int, device, seed: int = 0):
+    """Device-resident environment standing for ``cfg['env']`` — what ``envs.create_env_wrapper`` would build on
+    the host when no gym is installed — or ``None`` (a simulator that only exists on the host)."""
+    name = str(cfg["env"])
+    limit = int(cfg["max_ep_length"])
+    if cfg.get("synthetic_env"):
+        return DeviceSynthetic(name, num_envs, cfg["state_dim"], cfg["action_dim"], device, seed, time_limit=limit)
+    if name.startswith("Pendulum"):
+        return DevicePendulum(num_envs, device, seed, time_limit=min(200, limit))
+    from .gym_adapter import gym_available
+    if gym_available():
+        return None
+    if name == "InvertedPendulum-v2":
+        return DeviceCartPole(num_envs, device, seed, time_limit=limit)
+    return DeviceSynthetic(name, num_envs, cfg["state_dim"], cfg["action_dim"], device, seed, time_limit=limit)

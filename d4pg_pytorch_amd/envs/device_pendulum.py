@@ -69,11 +69,3 @@ class DevicePendulum:
         d_total, d_count = total - self._seen[0], count - self._seen[1]
         self._seen = (total, count)
         return (d_total / d_count if d_count else None), d_count
-
-
-def make_device_env(cfg, num_envs: int, device, seed: int = 0):
-    """Device-resident environment for ``cfg['env']`` or ``None`` when there is none (everything else is
-    stepped on the host)."""
-    if str(cfg["env"]).startswith("Pendulum") and not cfg.get("synthetic_env"):
-        return DevicePendulum(num_envs, device, seed, time_limit=min(200, int(cfg["max_ep_length"])))
-    return None

@@ -471,7 +471,7 @@ class Learner:
         if n_envs <= 0 or self.device.type != "cuda":
             return None
         from ..actors.gpu_rollout import DeviceRollout
-        from ..envs.device_pendulum import make_device_env
+        from ..envs.device_envs import make_device_env
         seed = int(cfg["random_seed"]) + 7919 * (self.rank + 1)
         env = make_device_env(cfg, n_envs, self.device, seed)
         if env is None:

@@ -283,6 +283,21 @@ class PendulumArgs(C.Structure):
                 ("reward_scale", C.c_float), ("limit_terminal", C.c_int)]
 
 
+class CartPoleArgs(C.Structure):
+    _fields_ = [("state", vp), ("t", vp), ("ep_return", vp), ("action", vp), ("obs", vp), ("next_obs", vp),
+                ("reward", vp), ("done", vp), ("trunc", vp), ("noise", vp), ("stats", vp), ("counter", vp),
+                ("seed", C.c_ulonglong), ("E", C.c_int), ("ld_act", C.c_int), ("time_limit", C.c_int), ("init", C.c_int),
+                ("limit_terminal", C.c_int), ("pad_", C.c_int)]
+
+
+class SyntheticEnvArgs(C.Structure):
+    _fields_ = [("state", vp), ("t", vp), ("ep_return", vp), ("M", vp), ("N", vp), ("action", vp), ("obs", vp),
+                ("next_obs", vp), ("reward", vp), ("done", vp), ("trunc", vp), ("noise", vp), ("stats", vp),
+                ("counter", vp), ("seed", C.c_ulonglong), ("E", C.c_int), ("S", C.c_int), ("A", C.c_int),
+                ("ld_act", C.c_int), ("time_limit", C.c_int), ("init", C.c_int), ("terminal_prob", C.c_float),
+                ("noise_std", C.c_float)]
+
+
 class RolloutRowsArgs(C.Structure):
     _fields_ = [("obs", vp), ("act", vp), ("next_obs", vp), ("R", vp), ("gk", vp), ("nxt", vp), ("d", vp), ("rows", vp),
                 ("T", C.c_int), ("E", C.c_int), ("S", C.c_int), ("A", C.c_int), ("ld_act", C.c_int), ("row_ld", C.c_int)]
@@ -374,6 +389,8 @@ def lib() -> C.CDLL:
             ("d4pg_actor_infer32", [C.POINTER(ActorInferArgs32), C.c_int, vp]),
             ("d4pg_pack_actor32", [C.POINTER(PackActorArgs32), vp]),
             ("d4pg_pendulum_step", [C.POINTER(PendulumArgs), vp]),
+            ("d4pg_cartpole_step", [C.POINTER(CartPoleArgs), vp]),
+            ("d4pg_synthetic_env_step", [C.POINTER(SyntheticEnvArgs), vp]),
             ("d4pg_rollout_rows", [C.POINTER(RolloutRowsArgs), vp]),
             ("d4pg_ipc_alloc", [C.c_size_t, C.POINTER(vp), C.c_char_p]),
             ("d4pg_ipc_open", [C.c_char_p, C.POINTER(vp)]),

@@ -19,11 +19,17 @@ import torch
 from ..config import default_config
 
 
-def pendulum_config(model: str, core: str, seed: int, **overrides) -> Dict:
-    cfg = dict(env="Pendulum-v0", model=model, batch_size=256, dense_size=400, device="cuda", n_step_returns=5,
+#: value support in the units the learner sees, per environment (pendulum: reward / 100 with gamma 0.99;
+#: cart-pole stand-in: +1 per step)
+SUPPORT = {"Pendulum-v0": (-20.0, 0.0), "InvertedPendulum-v2": (0.0, 100.0)}
+
+
+def pendulum_config(model: str, core: str, seed: int, env: str = "Pendulum-v0", **overrides) -> Dict:
+    v_min, v_max = SUPPORT.get(env, (-100.0, 100.0))
+    cfg = dict(env=env, model=model, batch_size=256, dense_size=400, device="cuda", n_step_returns=5,
                discount_rate=0.99, tau=0.001, critic_learning_rate=5e-4, actor_learning_rate=5e-4,
                replay_mem_size=1_000_000, replay_memory_prioritized=0, random_seed=seed,
-               v_min=-20.0, v_max=0.0,          # support in the units the learner sees (reward / 100, gamma 0.99)
+               v_min=v_min, v_max=v_max,
                compute_dtype="bf16" if core == "bf16" else "fp32",
                fused_learner="torch" if core == "torch" else "auto")
     cfg.update(overrides)
@@ -48,48 +54,55 @@ class _TorchSampler:
 
 
 class GreedyEvaluator:
-    """Mean undiscounted return of the greedy policy over ``envs`` fresh 200-step pendulum episodes."""
+    """Mean undiscounted return of the greedy policy over the first episode of each of ``envs`` fresh device
+    environments (pendulum: 200 steps each)."""
 
     def __init__(self, cfg: Dict, envs: int, device, seed: int):
         from ..actors.gpu_actor import PackedActor32
-        from ..envs.device_pendulum import DevicePendulum
+        from ..envs.device_envs import make_device_env
         self.device = torch.device(device)
-        self.env = DevicePendulum(envs, device, seed=seed)
-        self.actor = PackedActor32(3, 1, int(cfg["dense_size"]), device)
+        self.env = make_device_env(cfg, envs, device, seed)
+        S, A = self.env.state_dim, self.env.action_dim
+        self.actor = PackedActor32(S, A, int(cfg["dense_size"]), device)
         self.scale = float(cfg["action_high"]) if cfg.get("scale_action") else 1.0
         z = lambda *s: torch.zeros(*s, device=self.device)      # noqa: E731
-        self.obs, self.nobs, self.act = z(envs, 3), z(envs, 3), z(envs, 4)
+        self.obs, self.nobs, self.act = z(envs, S), z(envs, S), z(envs, 4 * ((A + 3) // 4))
         self.rew, self.done, self.trunc = z(envs), z(envs), z(envs)
+        self.first = z(envs)         # return of the first episode of every environment
+        self.alive = z(envs)
 
     def __call__(self, flat_ptr: int, actor_base: int) -> float:
         from ..actors.gpu_actor import PackedActor32
         from ..ops import hip as H
         self.actor.pack_from(flat_ptr, actor_base)
         self.env.reset(self.obs)
-        self.env.episode_stats()
+        self.first.zero_()
+        self.alive.fill_(1.0)
         mt = PackedActor32.tile_rows(self.env.E)
+        scale = float(getattr(self.env, "reward_scale", 1.0))
         for _ in range(self.env.time_limit):
             a = self.actor.infer_args(self.obs, self.act, self.env.E, self.scale)
             H._check(H.lib().d4pg_actor_infer32(a, mt, H.stream_ptr()), "d4pg_actor_infer32")
             self.env.step(self.act, self.obs, self.nobs, self.rew, self.done, self.trunc)
-        mean_ret, n = self.env.episode_stats()
-        assert n == self.env.E
-        return float(mean_ret)
+            self.first.add_(self.rew * self.alive, alpha=scale)          # rewards of the first episode only
+            self.alive.mul_(1.0 - torch.clamp(self.done + self.trunc, max=1.0))
+        return float(self.first.mean().item())
 
 
 def train_pendulum_on_device(model: str = "d4pg", core: str = "fp32", updates: int = 20_000, seed: int = 0,
                              eval_every: int = 1000, envs: int = 8, segment: int = 32, eval_envs: int = 64,
-                             warmup_segments: int = 8, device="cuda", **overrides) -> Dict:
-    """Train on the device pendulum; returns the evaluation curve and summary numbers.
+                             warmup_segments: int = 8, device="cuda", env: str = "Pendulum-v0", **overrides) -> Dict:
+    """Train on a device-resident environment (the pendulum by default; ``env="InvertedPendulum-v2"`` is the
+    cart-pole stand-in); returns the evaluation curve and summary numbers.
 
     ``core``: ``"torch"`` (eager PyTorch fp32, the oracle), ``"fp32"`` (fused HIP, default compute path) or
     ``"bf16"`` (fused HIP, bf16 MFMA operands).  ``envs * segment`` environment steps are collected per 32
     updates (8 per update by default)."""
     from ..actors.gpu_rollout import DeviceRollout
-    from ..envs.device_pendulum import DevicePendulum
+    from ..envs.device_envs import make_device_env
     from ..models.core import build_core
     from ..replay.hbm_replay import HbmReplay
-    cfg = pendulum_config(model, core, seed, **overrides)
+    cfg = pendulum_config(model, core, seed, env, **overrides)
     torch.manual_seed(seed)
     c = build_core(cfg, device, seed=seed)
     rp = HbmReplay(cfg, device, c.dev_state) if hasattr(c, "dev_state") else None
@@ -101,7 +114,7 @@ def train_pendulum_on_device(model: str = "d4pg", core: str = "fp32", updates: i
     if fused:
         c.attach_replay(rp)
     sampler = None if fused else _TorchSampler(rp, int(cfg["batch_size"]), seed)
-    ro = DeviceRollout(cfg, DevicePendulum(envs, device, seed=seed + 1), rp, device, segment=segment, seed=seed + 2)
+    ro = DeviceRollout(cfg, make_device_env(cfg, envs, device, seed + 1), rp, device, segment=segment, seed=seed + 2)
     ev = GreedyEvaluator(cfg, eval_envs, device, seed + 3)
     base_a = c.layout.actor.base
     for _ in range(warmup_segments):            # random-ish data before the first update (min_replay_size)
@@ -132,7 +145,7 @@ def train_pendulum_on_device(model: str = "d4pg", core: str = "fp32", updates: i
     rets = [r for _, r in curve]
     first: Optional[int] = next((s for s, r in curve if r > -300.0), None)
     m = c.read_metrics()
-    return {"model": model, "core": core, "core_class": type(c).__name__, "seed": seed, "updates": step,
+    return {"env": env, "model": model, "core": core, "core_class": type(c).__name__, "seed": seed, "updates": step,
             "env_steps": ro.env_steps, "wall_s": round(wall, 1), "curve": [(s, round(r, 1)) for s, r in curve],
             "initial_return": round(rets[0], 1), "final_return": round(rets[-1], 1),
             "last5_mean_return": round(sum(rets[-5:]) / len(rets[-5:]), 1), "best_return": round(max(rets), 1),

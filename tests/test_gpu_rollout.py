@@ -175,3 +175,101 @@ def test_learner_trains_from_device_rollouts():
     assert np.isfinite(m["value_loss"]) and np.isfinite(m["policy_loss"])
     mean_ret, n_ep = ro.episode_stats()
     assert n_ep > 0 and -400 < mean_ret < 0      # 20-step episodes
+
+
+def test_device_cartpole_follows_the_host_cartpole():
+    from d4pg_pytorch_amd.envs.device_envs import DeviceCartPole
+    from d4pg_pytorch_amd.envs.synthetic import CartPoleContinuousVec
+    E = 128
+    dev = DeviceCartPole(E, "cuda", seed=3, time_limit=60)
+    obs = torch.zeros(E, 4, device="cuda")
+    dev.reset(obs)
+    torch.cuda.synchronize()
+    assert obs.abs().max() <= 0.05 + 1e-6 and torch.equal(obs, dev.state)
+    host = CartPoleContinuousVec(E, seed=0, time_limit=60)
+    host.reset()
+    host.state[:] = dev.state.cpu().double().numpy()
+    nobs, rew, done, trunc = (torch.zeros(E, 4, device="cuda"), torch.zeros(E, device="cuda"),
+                              torch.zeros(E, device="cuda"), torch.zeros(E, device="cuda"))
+    g = torch.Generator().manual_seed(4)
+    fell_total = 0
+    for t in range(150):
+        act = (torch.rand(E, 4, generator=g) * 3 - 1.5).cuda()           # beyond [-1, 1]: clipped on both sides
+        dev.step(act, obs, nobs, rew, done, trunc)
+        torch.cuda.synchronize()
+        o_h, r_h, d_h = host._step(act[:, :1].cpu().numpy())
+        np.testing.assert_allclose(nobs.cpu().numpy(), o_h, rtol=1e-4, atol=1e-5)
+        assert np.array_equal(done.cpu().numpy() > 0.5, d_h) and (rew == 1).all() and not trunc.any()
+        fell_total += int(d_h.sum())
+        ended = torch.from_numpy(d_h).cuda()
+        # where an episode ended the policy sees a fresh state, elsewhere the next state
+        assert torch.equal(obs[~ended], nobs[~ended]) and (obs[ended].abs() <= 0.05 + 1e-6).all()
+        assert (dev.t[ended] == 0).all()
+        host.state[:] = dev.state.cpu().double().numpy()                  # follow the device (resets, fp32 rounding)
+        host.t[:] = dev.t.cpu().numpy()
+    mean_ret, n = dev.episode_stats()
+    assert n == fell_total > E and 5 < mean_ret <= 60
+
+
+def test_device_synthetic_env_follows_the_host_dynamics():
+    from d4pg_pytorch_amd.envs.device_envs import DeviceSynthetic
+    from d4pg_pytorch_amd.envs.synthetic import SyntheticVec
+    E, S, A = 32, 111, 8                                                   # the Ant shape
+    dev = DeviceSynthetic("Ant-v2", E, S, A, "cuda", seed=1, time_limit=25, terminal_prob=0.0, noise_std=0.0)
+    host = SyntheticVec("Ant-v2", E, S, A, seed=0, episode_len=25, terminal_prob=0.0)
+    obs = torch.zeros(E, S, device="cuda")
+    dev.reset(obs)
+    torch.cuda.synchronize()
+    assert 0.3 < obs.std().item() < 0.7                                   # N(0, 0.5^2) starts
+    host.reset()
+    host.s[:] = obs.cpu().numpy()
+    nobs, rew, done, trunc = (torch.zeros(E, S, device="cuda"), torch.zeros(E, device="cuda"),
+                              torch.zeros(E, device="cuda"), torch.zeros(E, device="cuda"))
+    g = torch.Generator().manual_seed(2)
+    for t in range(30):
+        act = (torch.rand(E, A, generator=g) * 2 - 1).cuda()
+        dev.step(act, obs, nobs, rew, done, trunc)
+        torch.cuda.synchronize()
+        a = act.cpu().numpy()
+        want = np.tanh(host.s @ host.M + a @ host.N)
+        np.testing.assert_allclose(nobs.cpu().numpy(), want, rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(rew.cpu().numpy(), -(want ** 2).mean(1) - 0.01 * (a ** 2).sum(1), rtol=1e-4, atol=1e-5)
+        assert bool(done.all()) == (t == 24) and bool(done.any()) == (t == 24)
+        host.s[:] = obs.cpu().numpy()                                     # (fresh states after the time limit)
+    assert dev.episode_stats()[1] == E
+
+
+def test_rollout_with_terminal_states_equals_the_host_nstep_assembler():
+    """Cart-pole under heavy exploration noise: episodes END (done = 1) inside the segments, so the device n-step
+    rows must stop their windows there and carry the terminal flag, like the host assembler's."""
+    from d4pg_pytorch_amd.actors.gpu_rollout import DeviceRollout
+    from d4pg_pytorch_amd.actors.native import NStepAssembler
+    from d4pg_pytorch_amd.envs.device_envs import make_device_env
+    from d4pg_pytorch_amd.models.core import build_core
+    from d4pg_pytorch_amd.replay.hbm_replay import HbmReplay
+    cfg = default_config(env="InvertedPendulum-v2", model="d3pg", batch_size=64, dense_size=128, device="cuda",
+                         n_step_returns=5, replay_mem_size=20_000, ou_max_sigma=1.0, random_seed=3)
+    core = build_core(cfg, "cuda")
+    rp = HbmReplay(cfg, "cuda", core.dev_state)
+    env = make_device_env(cfg, 64, "cuda", seed=3)
+    assert type(env).__name__ == "DeviceCartPole"
+    ro = DeviceRollout(cfg, env, rp, "cuda", segment=24, seed=3)
+    ro.refresh_weights(core.online.flat.data_ptr(), core.layout.actor.base)
+    T, E, S, A, n = ro.T, ro.E, ro.S, ro.A, ro.n
+    terminals = 0
+    for seg in range(3):
+        ro.collect()
+        torch.cuda.synchronize()
+        obs, act, nobs = ro.obs[:T].cpu().numpy(), ro.act.cpu().numpy()[:, :, :A], ro.next_obs.cpu().numpy()
+        rew, done = ro.reward.cpu().numpy(), ro.done.cpu().numpy() > 0.5
+        terminals += int(done.sum())
+        got = ro.rows.cpu().numpy().reshape(T, E, -1)
+        for e in range(E):
+            asm = NStepAssembler(1, n, S, A, cfg["discount_rate"])
+            out = []
+            for t in range(T):
+                out.extend(asm.push(obs[t, e], act[t, e], rew[t, e], nobs[t, e], done[t, e: e + 1], np.array([t == T - 1])))
+            want = np.stack(out)
+            np.testing.assert_allclose(got[:, e, : 2 * S + A + 3], want[:, : 2 * S + A + 3], rtol=1e-6, atol=1e-7)
+        assert (got[:, :, S + A + 1][done] == 1).all()                    # the step that ended an episode is terminal
+    assert terminals > 20

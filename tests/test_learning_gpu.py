@@ -30,3 +30,12 @@ def test_same_seed_same_run():
     a = train_pendulum_on_device("d3pg", "fp32", updates=1500, seed=5, eval_every=500)
     b = train_pendulum_on_device("d3pg", "fp32", updates=1500, seed=5, eval_every=500)
     assert a["curve"] == b["curve"]
+
+
+def test_d3pg_learns_to_balance_the_device_cartpole():
+    """A task with terminal states (the pole falls): random actions last ~25 steps, a trained policy hundreds."""
+    from d4pg_pytorch_amd.utils.learning import train_pendulum_on_device
+    r = train_pendulum_on_device("d3pg", "fp32", updates=6000, seed=100, eval_every=1000, env="InvertedPendulum-v2",
+                                 max_ep_length=500)
+    assert r["initial_return"] < 120
+    assert r["best_return"] > 300, r["curve"]
