@@ -28,6 +28,7 @@
 #include <fcntl.h>
 #include <new>
 #include <sys/mman.h>
+#include <sched.h>
 #include <sys/stat.h>
 #include <thread>
 #include <unistd.h>
@@ -412,7 +413,14 @@ API void slab_publish(void* h, const float* src, int64_t update_step) {
 // Returns 1 (new snapshot), 0 (unchanged or nothing published yet), -1 (gave up: writer stuck).
 API int slab_read(void* h, float* dst, uint64_t* last_version) {
     auto* s = static_cast<Slab*>(h);
-    for (int attempt = 0; attempt < 100000; ++attempt) {
+    // A writer that was descheduled in the middle of a publication holds the version odd for a scheduling
+    // quantum or more on a loaded host, so "stuck" is decided by the wall clock (2 s), not by a spin count.
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(2);
+    for (uint64_t attempt = 0;; ++attempt) {
+        if ((attempt & 1023) == 1023) {
+            if (std::chrono::steady_clock::now() > deadline) break;
+            sched_yield();
+        }
         const uint64_t v1 = s->hdr->version.load(std::memory_order_acquire);
         if (v1 & 1) {
             cpu_relax();
