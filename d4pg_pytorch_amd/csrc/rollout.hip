@@ -219,6 +219,166 @@ D4PG_API int d4pg_cartpole_step(const CartPoleArgs* a, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Lunar lander with continuous engines (envs/lunar_lander.py::LunarLanderVec, the task of LunarLanderContinuous-v2
+// as a planar rigid body with spring-damper feet): the same arithmetic in fp32, one thread per environment.
+// Constants are those of the host class; change them together.
+struct LanderArgs {
+    float* state;            // [E][12] x, y, vx, vy, theta, omega, contact0, contact1, previous shaping, rest steps, 0, 0
+    int* t;                  // [E]
+    float* ep_return;        // [E] running UNSCALED episode return
+    const float* action;     // [E][ld_act] main engine, side engines
+    float* obs;              // [E][8] what the policy sees next (a fresh state where an episode ended)
+    float* next_obs;         // [E][8] the observation that followed the action
+    float* reward;           // [E] reward / reward_scale
+    float* done;             // [E] 1: crashed, flew out, landed (and the time limit, with limit_terminal)
+    float* trunc;            // [E] 1: time limit without limit_terminal
+    float* noise;            // [E][ld_act] exploration-noise state, zeroed where an episode ends; or null
+    double* stats;           // [2] sum of finished episode returns, number of finished episodes
+    unsigned long long* counter;
+    unsigned long long seed;
+    int E, ld_act, time_limit, init;
+    int limit_terminal;
+    float reward_scale;
+};
+namespace lander {
+constexpr float FPS = 50.f, W = 20.f, H = 400.f / 30.f, PAD_Y = H / 4.f, LEG_DOWN = 0.6f, FOOT_X = 20.f / 30.f;
+constexpr float HULL_HALF_W = 17.f / 30.f, HULL_BOTTOM = -10.f / 30.f, HULL_TOP = 17.f / 30.f, HULL_TOP_HALF_W = 14.f / 30.f;
+constexpr float MASS = 4.96f, INERTIA = 0.864f, GRAVITY = -10.f;
+constexpr float MAIN_ACC = 13.f * (4.f / 30.f) / MASS * FPS, SIDE_ACC = 0.6f * (12.f / 30.f) / MASS * FPS;
+constexpr float SIDE_ANG_ACC = 0.6f * (12.f / 30.f) * (14.f / 30.f) / INERTIA * FPS;
+constexpr int SUBSTEPS = 4, REST_STEPS = 20;
+constexpr float K_SPRING = 4000.f, C_DAMP = 120.f, C_FRICTION = 60.f, INIT_SPEED = 4.f;
+__device__ __forceinline__ void observe(const float* q, float c0, float c1, float* o) {
+    o[0] = (q[0] - W / 2.f) / (W / 2.f);
+    o[1] = (q[1] - (PAD_Y + LEG_DOWN)) / (H / 2.f);
+    o[2] = q[2] * (W / 2.f) / FPS;
+    o[3] = q[3] * (H / 2.f) / FPS;
+    o[4] = q[4];
+    o[5] = 20.f * q[5] / FPS;
+    o[6] = c0;
+    o[7] = c1;
+}
+__device__ __forceinline__ float shaping(const float* o) {
+    return -100.f * sqrtf(o[0] * o[0] + o[1] * o[1]) - 100.f * sqrtf(o[2] * o[2] + o[3] * o[3]) - 100.f * fabsf(o[4]) +
+           10.f * o[6] + 10.f * o[7];
+}
+}  // namespace lander
+__global__ __launch_bounds__(256) void lander_step_kernel(const LanderArgs a) {
+    using namespace lander;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long ctr = *a.counter;
+    if (e >= a.E) return;
+    float* st = a.state + (size_t)e * 12;
+    float q[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) q[i] = st[i];
+    float c0 = st[6], c1 = st[7], prev = st[8], rest = st[9];
+    int t = a.t[e];
+    bool reset = a.init != 0;
+    if (!a.init) {
+        const float a0 = fminf(1.f, fmaxf(-1.f, a.action[(size_t)e * a.ld_act]));
+        const float a1 = fminf(1.f, fmaxf(-1.f, a.action[(size_t)e * a.ld_act + 1]));
+        const float main_p = a0 > 0.f ? 0.5f + 0.5f * a0 : 0.f;
+        const float side = fabsf(a1) > 0.5f ? a1 : 0.f;
+        const float h = 1.f / (FPS * SUBSTEPS);
+        c0 = c1 = 0.f;
+        for (int sub = 0; sub < SUBSTEPS; ++sub) {
+            const float s = sinf(q[4]), c = cosf(q[4]);
+            float ax = -s * MAIN_ACC * main_p + c * SIDE_ACC * side;
+            float ay = c * MAIN_ACC * main_p + s * SIDE_ACC * side + GRAVITY;
+            float alpha = -SIDE_ANG_ACC * side;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float fxb = k == 0 ? -FOOT_X : FOOT_X;
+                const float rx = c * fxb + s * LEG_DOWN, ry = s * fxb - c * LEG_DOWN;
+                const float pen = PAD_Y - (q[1] + ry);
+                if (pen > 0.f) {
+                    const float fvx = q[2] - q[5] * ry, fvy = q[3] + q[5] * rx;
+                    const float fn = fmaxf(0.f, K_SPRING * pen - C_DAMP * fvy), ft = -C_FRICTION * fvx;
+                    ax += ft / MASS;
+                    ay += fn / MASS;
+                    alpha += (rx * fn - ry * ft) / INERTIA;
+                    if (k == 0) c0 = 1.f; else c1 = 1.f;
+                }
+            }
+            q[2] += h * ax;
+            q[3] += h * ay;
+            q[5] += h * alpha;
+            q[0] += h * q[2];
+            q[1] += h * q[3];
+            q[4] += h * q[5];
+        }
+        t += 1;
+        const float s = sinf(q[4]), c = cosf(q[4]);
+        const float lowest = fminf(fminf(q[1] - s * HULL_HALF_W + c * HULL_BOTTOM, q[1] + s * HULL_HALF_W + c * HULL_BOTTOM),
+                                   fminf(q[1] - s * HULL_TOP_HALF_W + c * HULL_TOP, q[1] + s * HULL_TOP_HALF_W + c * HULL_TOP));
+        float o[8];
+        observe(q, c0, c1, o);
+        const float sh = shaping(o);
+        float rew = sh - prev - 0.30f * main_p - 0.03f * fabsf(side);
+        prev = sh;
+        const bool still = c0 > 0.f && c1 > 0.f && sqrtf(q[2] * q[2] + q[3] * q[3]) < 0.05f && fabsf(q[5]) < 0.05f;
+        rest = still ? rest + 1.f : 0.f;
+        const bool landed = rest >= (float)REST_STEPS;
+        const bool failed = lowest < PAD_Y || fabsf(o[0]) >= 1.f;
+        rew = failed ? -100.f : (landed ? 100.f : rew);
+        const bool limit = a.time_limit > 0 && t >= a.time_limit;
+        const bool term = failed || landed;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a.next_obs[(size_t)e * 8 + i] = o[i];
+        a.reward[e] = rew / a.reward_scale;
+        a.done[e] = (term || (limit && a.limit_terminal)) ? 1.f : 0.f;
+        a.trunc[e] = (limit && !term && !a.limit_terminal) ? 1.f : 0.f;
+        const float ret = a.ep_return[e] + rew;
+        reset = term || limit;
+        if (reset) {
+            atomicAdd(&a.stats[0], (double)ret);
+            atomicAdd(&a.stats[1], 1.0);
+        }
+        a.ep_return[e] = reset ? 0.f : ret;
+    }
+    if (reset) {
+        uint32_t r[4];
+        philox4x32((uint32_t)e, (uint32_t)ctr, (uint32_t)(ctr >> 32), 0x1A4DE2u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), r);
+        q[0] = W / 2.f;
+        q[1] = H;
+        q[2] = ((float)(r[0] >> 8) * (1.0f / 16777216.0f) * 2.f - 1.f) * INIT_SPEED;
+        q[3] = ((float)(r[1] >> 8) * (1.0f / 16777216.0f) * 2.f - 1.f) * INIT_SPEED;
+        q[4] = q[5] = 0.f;
+        c0 = c1 = rest = 0.f;
+        float o[8];
+        observe(q, 0.f, 0.f, o);
+        prev = shaping(o);
+        t = 0;
+        if (a.init) a.ep_return[e] = 0.f;
+        if (a.noise != nullptr)
+            for (int j = 0; j < a.ld_act; ++j) a.noise[(size_t)e * a.ld_act + j] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) st[i] = q[i];
+    st[6] = c0;
+    st[7] = c1;
+    st[8] = prev;
+    st[9] = rest;
+    a.t[e] = t;
+    float o[8];
+    observe(q, c0, c1, o);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a.obs[(size_t)e * 8 + i] = o[i];
+}
+D4PG_API int d4pg_lander_step(const LanderArgs* a, hipStream_t stream) {
+    if (a->E < 1 || a->state == nullptr || a->t == nullptr || a->obs == nullptr || a->counter == nullptr ||
+        a->ep_return == nullptr || !(a->reward_scale > 0.f))
+        return -1;
+    if (!a->init && (a->action == nullptr || a->next_obs == nullptr || a->reward == nullptr || a->done == nullptr ||
+                     a->trunc == nullptr || a->stats == nullptr || a->ld_act < 2))
+        return -2;
+    hipLaunchKernelGGL(lander_step_kernel, dim3((a->E + 255) / 256), dim3(256), 0, stream, *a);
+    hipLaunchKernelGGL(rollout_counter_kernel, dim3(1), dim3(64), 0, stream, a->counter);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Shape-only environment of any observation / action size (envs/synthetic.py::SyntheticVec): a fixed random
 // contraction s' = tanh(s M + a N + noise), reward -mean(s'^2) - 0.01 |a|^2, episodes end by time limit or with a
 // small probability per step.  Two kernels per step: the new states (one thread per state component, reading
@@ -404,3 +564,4 @@ D4PG_SIZEOF(PendulumArgs)
 D4PG_SIZEOF(RolloutRowsArgs)
 D4PG_SIZEOF(CartPoleArgs)
 D4PG_SIZEOF(SyntheticEnvArgs)
+D4PG_SIZEOF(LanderArgs)

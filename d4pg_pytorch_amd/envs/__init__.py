@@ -7,7 +7,8 @@ Resolution order for ``config['env']``:
 3. gym / gymnasium, if installed -> :class:`GymVec` (reward /100 for Pendulum and
    LunarLanderContinuous like ``env/pendulum.py:13-14`` and
    ``env/lunar_lander_continous.py:12-13``; identity otherwise)
-4. native analytic stand-in of the same shape (``InvertedPendulum-v2`` -> cart-pole)
+4. native implementation of the task (``LunarLanderContinuous-v2`` -> :class:`LunarLanderVec`, own planar
+   rigid-body simulation) or analytic stand-in of the same shape (``InvertedPendulum-v2`` -> cart-pole)
 5. shape-only synthetic environment (with a warning), so that every shipped
    configuration can at least run its full pipeline.
 """
@@ -17,6 +18,7 @@ import warnings
 
 from .base import BoxSpace, VecEnv
 from .gym_adapter import GymVec, gym_available
+from .lunar_lander import LunarLanderVec
 from .pendulum import PendulumVec
 from .synthetic import CartPoleContinuousVec, SyntheticVec
 from .wrappers import BipedalWalker, EnvWrapper, LunarLanderContinous, PendulumWrapper  # noqa: E402,F401
@@ -38,6 +40,8 @@ def create_env_wrapper(config, num_envs=None, seed=None) -> VecEnv:
             return GymVec(name, E, S, A, lo, hi, seed, REWARD_SCALE.get(name, 1.0))
         except Exception as exc:   # unknown id, missing simulator backend, ...
             warnings.warn(f"gym could not create '{name}' ({exc}); using a stand-in", stacklevel=2)
+    if name.startswith("LunarLanderContinuous"):
+        return LunarLanderVec(E, seed, time_limit=config["max_ep_length"], env_name=name)
     if name == "InvertedPendulum-v2":
         return CartPoleContinuousVec(E, seed, time_limit=config["max_ep_length"], env_name=name)
     warnings.warn(f"no simulator for '{name}': using the shape-only synthetic environment "
@@ -47,6 +51,6 @@ def create_env_wrapper(config, num_envs=None, seed=None) -> VecEnv:
     return env
 
 
-__all__ = ["create_env_wrapper", "VecEnv", "BoxSpace", "PendulumVec", "SyntheticVec",
+__all__ = ["create_env_wrapper", "VecEnv", "BoxSpace", "PendulumVec", "LunarLanderVec", "SyntheticVec",
            "CartPoleContinuousVec", "GymVec", "gym_available",
            "EnvWrapper", "PendulumWrapper", "LunarLanderContinous", "BipedalWalker"]

@@ -4,6 +4,8 @@
 * :class:`DeviceCartPole` — ``envs/synthetic.py::CartPoleContinuousVec`` (the stand-in with the shape of
   ``InvertedPendulum-v2``) as one kernel per step: an environment with TERMINAL states, so the device-side
   n-step assembly sees ``done`` flags that stop the bootstrap, not only time limits.
+* :class:`DeviceLunarLander` — ``envs/lunar_lander.py::LunarLanderVec`` (the task of ``LunarLanderContinuous-v2``:
+  engines, spring-damper feet, shaped reward, crash / landing terminals), one thread per environment.
 * :class:`DeviceSynthetic` — ``envs/synthetic.py::SyntheticVec`` for any observation / action shape (the same
   fixed dynamics matrices), so that the throughput configurations (Ant: 111 / 8, ...) can run their explorers
   on the GPU as well.
@@ -87,6 +89,25 @@ class DeviceCartPole(_DeviceEnvBase):
         H.launch("d4pg_cartpole_step", a)
 
 
+class DeviceLunarLander(_DeviceEnvBase):
+    reward_scale = 100.0         # env/lunar_lander_continous.py:12-13
+
+    def __init__(self, num_envs: int, device="cuda", seed: int = 0, time_limit: int = 1000, limit_terminal: bool = True):
+        super().__init__(num_envs, 8, 2, device, seed, time_limit)
+        # x, y, vx, vy, theta, omega, contacts, previous shaping, rest steps (csrc/rollout.hip, LanderArgs)
+        self.state = torch.zeros(self.E, 12, dtype=torch.float32, device=self.device)
+        self.limit_terminal = bool(limit_terminal)
+
+    def _args(self, init: int) -> H.LanderArgs:
+        a = H.LanderArgs()
+        self._fill(a, init)
+        a.limit_terminal, a.reward_scale = int(self.limit_terminal), self.reward_scale
+        return a
+
+    def _launch(self, a) -> None:
+        H.launch("d4pg_lander_step", a)
+
+
 class DeviceSynthetic(_DeviceEnvBase):
     def __init__(self, env_name: str, num_envs: int, state_dim: int, action_dim: int, device="cuda", seed: int = 0,
                  time_limit: int = 1000, terminal_prob: float = 0.001, noise_std: float = 0.05):
@@ -122,4 +143,6 @@ def make_device_env(cfg, num_envs: int, device, seed: int = 0):
         return None
     if name == "InvertedPendulum-v2":
         return DeviceCartPole(num_envs, device, seed, time_limit=limit)
+    if name.startswith("LunarLanderContinuous"):
+        return DeviceLunarLander(num_envs, device, seed, time_limit=limit)
     return DeviceSynthetic(name, num_envs, cfg["state_dim"], cfg["action_dim"], device, seed, time_limit=limit)

@@ -20,8 +20,8 @@ from ..config import default_config
 
 
 #: value support in the units the learner sees, per environment (pendulum: reward / 100 with gamma 0.99;
-#: cart-pole stand-in: +1 per step)
-SUPPORT = {"Pendulum-v0": (-20.0, 0.0), "InvertedPendulum-v2": (0.0, 100.0)}
+#: cart-pole stand-in: +1 per step; lunar lander: reward / 100, episode returns between about -4 and +3)
+SUPPORT = {"Pendulum-v0": (-20.0, 0.0), "InvertedPendulum-v2": (0.0, 100.0), "LunarLanderContinuous-v2": (-5.0, 5.0)}
 
 
 def pendulum_config(model: str, core: str, seed: int, env: str = "Pendulum-v0", **overrides) -> Dict:

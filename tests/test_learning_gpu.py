@@ -39,3 +39,14 @@ def test_d3pg_learns_to_balance_the_device_cartpole():
                                  max_ep_length=500)
     assert r["initial_return"] < 120
     assert r["best_return"] > 300, r["curve"]
+
+
+def test_d4pg_learns_to_land_the_lunar_lander():
+    """The reference's second benchmark task (``configs/lunar_lander_continuous_d4pg.yml``, README curve) on the
+    native lander with the reference's hyper-parameters: a fresh policy crashes (about -100 .. -300), a trained
+    one lands (+100 bonus; >= 200 is the conventional solved level of the task)."""
+    from d4pg_pytorch_amd.utils.learning import train_pendulum_on_device
+    r = train_pendulum_on_device("d4pg", "fp32", updates=12_000, seed=200, eval_every=2000, envs=16,
+                                 env="LunarLanderContinuous-v2", max_ep_length=1000)
+    assert r["initial_return"] < 0
+    assert r["best_return"] > 200 and r["final_return"] > 150, r["curve"]
