@@ -178,7 +178,8 @@ __device__ __forceinline__ void warm_layer(const LayerW32& L, int slice, int nsl
 
 // ---- arguments (mirrored in ops/hip.py; the layouts of csrc/fused.hip with fp32 pointers) --------
 struct CriticAhead32 {
-    int mode;        // 0: off; 1: only while the next batch is in the same chunk buffer; 2: always
+    int mode;        // 0: off; 1: only while the next batch is in the same chunk buffer; 2: always;
+                     // 3: prioritised replay, the workgroups of the pass draw their rows of the next batch first
     int pad_;
     float* h1;       // [B][ldh] relu(layer 1) row tiles (LDS images)
     float* h2;       // [B][ldh]
@@ -236,6 +237,7 @@ struct ActorPhaseArgs32 {
     float* c_h1T;
     float* c_h2T;
     CriticAhead32 ahead;
+    const SampleArgs* smp;   // ahead.mode == 3: how the NEXT batch is drawn (prioritised replay)
 };
 
 __host__ __device__ __forceinline__ bool critic_red_aliased(const PhaseDims& d) { return (NW32 - 1) * 64 <= d.ldh; }
@@ -484,7 +486,7 @@ __global__ __launch_bounds__(64 * NW32) void critic_phase32_kernel(const CriticP
     // Was the online critic's forward pass on exactly these rows made ahead, after the last change of
     // the critic weights?  (wave-uniform; CriticAhead in csrc/fused.hip)
     bool ahead_ok = false;
-    if (a.ahead.mode != 0 && a.pk.enabled)
+    if (a.ahead.mode != 0 && (a.pk.enabled || a.ahead.mode == 3))
         ahead_ok = a.pk.st->pad_[AHEAD_STEP] == a.pk.st->step_done + 1 &&
                    a.pk.st->pad_[AHEAD_ROWS] == (long long)(uintptr_t)src_sa.base;
     STAMP(0, 0);
@@ -573,13 +575,22 @@ __global__ __launch_bounds__(64 * NW32) void critic_phase32_kernel(const CriticP
 }
 
 // ---- the online critic's forward pass for the NEXT update, in extra workgroups of the actor phase ----
+// Prioritised replay (ahead.mode == 3).  The batch of the next update can only be drawn once this update's
+// priorities are in the tree; the tree update rides in the launch BEFORE this one (the critic's weight-gradient
+// launch, wgrad32_kernel), so the tree is complete when this launch starts.  The workgroups here draw the rows
+// of their own tile (one wave per row, the sampling kernel's code and stream positions, hence the same rows)
+// into the learner's input buffers and go on with the forward pass: sampling and pass (~17 us) hide under the
+// actor role of the launch instead of following the update's last kernel.
 template <int MT, int KSH, int KSN>
 __device__ __forceinline__ void critic_ahead_role(const ActorPhaseArgs32& a, int row0, char* smem) {
     constexpr int M = 4 * MT;
     const PhaseDims& d = a.d;
-    const long long s_next = a.pk.st->step_done - a.pk.step0 + 1;
-    // mode 1: the next chunk buffer may still be receiving its rows (all-gather on another stream)
-    if (a.ahead.mode == 1 && s_next % a.pk.K == 0) return;
+    const bool per = a.ahead.mode == 3;
+    if (!per) {
+        const long long s_next = a.pk.st->step_done - a.pk.step0 + 1;
+        // mode 1: the next chunk buffer may still be receiving its rows (all-gather on another stream)
+        if (a.ahead.mode == 1 && s_next % a.pk.K == 0) return;
+    }
     int off = 0;
     auto carve = [&](int bytes) { char* p = smem + off; off += (bytes + 15) & ~15; return p; };
     float* xin = (float*)carve(M * d.ldx * 4);
@@ -591,7 +602,19 @@ __device__ __forceinline__ void critic_ahead_role(const ActorPhaseArgs32& a, int
     ch.template prefetch_n<0>(a.cf[0]);
     zero_tail(bufC, d.ldh, M, d.H);
     zero_tail(bufD, d.ldh, M, d.H);
-    const RowSrc src = packed_src(a.pk, 0, 1);
+    RowSrc src;
+    if (per) {
+        const SampleArgs& sa = *a.smp;
+        const long long step = a.pk.st->step_cur;      // updates completed once this one is = stream position of the next
+        const long long size = sa.st->replay_size;
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        if (size > 0)
+            for (int r = wave; r < M; r += NW32) sample_row(sa, row0 + r, step, size, threadIdx.x & 63);
+        __syncthreads();                                            // the rows, to the other waves of this workgroup
+        src = plain_src(sa.sa, sa.ld_x, d.B);
+    } else {
+        src = packed_src(a.pk, 0, 1);
+    }
     const int ldh = d.ldh, nop = d.nop, Bp = d.Bp;
     float* const h1T = a.c_h1T;
     float* const h2T = a.c_h2T;
@@ -654,7 +677,7 @@ __global__ __launch_bounds__(64 * NW32) void actor_phase32_kernel(const ActorPha
         critic_ahead_role<MT, KSH, KSN>(a, (blockIdx.x - (d.B / M + n_tree)) * M, smem);
         return;
     }
-    if (row0 >= d.B) {         // the extra workgroup: priorities back into the tree
+    if (row0 >= d.B) {         // the extra workgroups: priorities back into the tree
         tree_update_body<NW32>(a.tree, (int)blockIdx.x - d.B / M, (int*)smem);
         return;
     }
@@ -952,11 +975,16 @@ D4PG_API int d4pg_actor_phase32(const ActorPhaseArgs32* a, int mt, hipStream_t s
                                             (a->tree.parts > 1 && (a->tree.t.L < 2 || a->tree.ticket == nullptr)))))
         return -11;
     if (a->ahead.mode != 0) {
-        if (a->ahead.mode < 0 || a->ahead.mode > 2 || !a->pk.enabled) return -15;
+        if (a->ahead.mode < 0 || a->ahead.mode > 3 || (a->ahead.mode != 3 && !a->pk.enabled)) return -15;
         if (a->ahead.h1 == nullptr || a->ahead.h2 == nullptr || a->ahead.lg == nullptr || a->c_saT == nullptr ||
             a->c_h1T == nullptr || a->c_h2T == nullptr)
             return -15;
-        if (int prc = check_packed(a->pk, d)) return prc;
+        if (a->ahead.mode == 3) {      // the batch of the next update is drawn inside the launch: the tree must be
+                                       // complete when it starts (its update rides in the launch before, d4pg_wgrad32)
+            if (a->smp == nullptr || a->pk.st == nullptr || a->pk.enabled || a->tree.n > 0) return -16;
+        } else if (int prc = check_packed(a->pk, d)) {
+            return prc;
+        }
     }
     const int n_ahead = a->ahead.mode != 0 ? d.B / M : 0;
     const int extra_blocks = (a->tree.n > 0 ? (a->tree.parts > 1 ? a->tree.parts : 1) : 0) + n_ahead + n_warmers32(d, M);
@@ -1022,7 +1050,8 @@ struct WgradGroup32 {
     WgradAdam opt;
     const SampleArgs* smp;     // prioritised replay: the next batch is drawn by extra workgroups (csrc/fused.hip)
     int smp_rows;
-    int pad2_;
+    int tree_parts;            // > 0: that many more workgroups write the update's priorities into the tree (*tree)
+    const TreeUpdateArgs* tree;
 };
 
 template <int NWV>
@@ -1032,6 +1061,10 @@ __global__ __launch_bounds__(64 * NWV) void wgrad32_kernel(const WgradGroup32 g)
     float* cs = wg_smem + NWV * 16 * 64;       // [NWV][32] partial row sums
     const int total = g.total_tiles;
     const int id = blockIdx.x;
+    if (g.tree_parts > 0 && id >= (int)gridDim.x - g.tree_parts) {      // the last workgroups: priorities into the tree
+        tree_update_body<NWV>(*g.tree, id - ((int)gridDim.x - g.tree_parts), (int*)wg_smem);
+        return;
+    }
     if (id == total) {          // the extra workgroup of a finishing launch
         wgrad_finish_role<NWV>(g.opt, cs);
         return;
@@ -1159,6 +1192,8 @@ static int launch_wgrad32(K kernel, int nwv, int grid, const WgradGroup32& g, hi
         if (!extra || g.smp_rows < 1) return -5;
         extra += (g.smp_rows + nwv - 1) / nwv;
     }
+    if (g.tree_parts < 0 || g.tree_parts > 64 || (g.tree_parts > 0 && g.tree == nullptr)) return -6;
+    extra += g.tree_parts;
     hipLaunchKernelGGL(kernel, dim3(grid + extra), dim3(64 * nwv), lds, stream, g);
     return (int)hipGetLastError();
 }

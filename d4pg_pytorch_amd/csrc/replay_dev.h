@@ -66,9 +66,10 @@ struct TreeUpdateArgs {
 };
 
 // NWAVES = waves of the calling workgroup (all of them must call this); part = 0 .. a.parts - 1;
-// flag = one int of LDS
+// flag = one int of LDS.  Returns true (to every thread) in the workgroup that leaves the tree complete:
+// the only one, or the last to finish of several.
 template <int NWAVES>
-__device__ __forceinline__ void tree_update_body(const TreeUpdateArgs& a, int part, int* flag) {
+__device__ __forceinline__ bool tree_update_body(const TreeUpdateArgs& a, int part, int* flag) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int W = a.parts > 1 ? a.parts : 1;
     const int L = a.t.L;
@@ -76,9 +77,14 @@ __device__ __forceinline__ void tree_update_body(const TreeUpdateArgs& a, int pa
     auto mine = [&](long long node, int level) {          // level <= L-1
         return W == 1 || (int)((node >> (top_shift - 6 * level)) % W) == part;
     };
+    // The slot of a thread's first item stays in a register: every level below would otherwise start with a
+    // load of it (the stores in between may alias) ahead of the loads of the children, two memory round trips
+    // per level instead of one.
+    const long long slot0 = tid < a.n ? a.idx[tid] : 0;
+    auto slot_of = [&](int i) { return i == tid ? slot0 : a.idx[i]; };
     float local_max = 0.f;
     for (int i = tid; i < a.n; i += 64 * NWAVES) {
-        const long long slot = a.idx[i];
+        const long long slot = slot_of(i);
         if (!mine(slot, 0)) continue;
         float p = a.prio[i];
         if (!(p > 0.f) || p > 3.0e38f) p = 1e-4f;   // NaN / inf / non-positive never enter the tree
@@ -110,13 +116,13 @@ __device__ __forceinline__ void tree_update_body(const TreeUpdateArgs& a, int pa
                 if (*flag) *a.ticket = 0u;             // ready for the next update (stream order)
             }
             __syncthreads();
-            if (!*flag) return;
+            if (!*flag) return false;
             __threadfence();
         }
         const bool whole = top || nodes * 8 <= (long long)a.n;
         const int tasks = whole ? (int)nodes : a.n;
         for (int i = tid; i < tasks; i += nthreads) {
-            const long long g = whole ? (long long)i : (a.idx[i] >> (6 * l));
+            const long long g = whole ? (long long)i : (slot_of(i) >> (6 * l));
             if (!top && !mine(g, l)) continue;
             double s = 0.0;
             float m = INFINITY;
@@ -162,6 +168,7 @@ __device__ __forceinline__ void tree_update_body(const TreeUpdateArgs& a, int pa
         }
         __syncthreads();
     }
+    return true;
 }
 
 // ---------------------------------------------------------------------------

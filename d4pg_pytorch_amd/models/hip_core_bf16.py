@@ -45,6 +45,9 @@ class HipCoreBf16(HipCore):
     _actor_args_cls = H.ActorPhaseArgs
     _fn_critic, _fn_actor = "d4pg_critic_phase", "d4pg_actor_phase"
     rows_per_tile_unit = 16          # a phase workgroup owns rows_per_tile_unit * mt batch rows
+    #: prioritised replay: the actor-phase launch can also draw the next batch (behind its own tree update) and
+    #: make the online critic's forward pass on it (``CriticAhead`` mode 3, csrc/fused32.hip)
+    supports_per_ahead = False
 
     def __init__(self, cfg: Dict, device="cuda", seed: Optional[int] = None):
         super().__init__(cfg, device, seed)
@@ -141,6 +144,16 @@ class HipCoreBf16(HipCore):
         sampling kernel at the start of every update."""
         return (self.replay is not None and self.replay.prioritized and self.grad_sync is None
                 and getattr(self, "_smp_dev", None) is not None and bool(int(os.environ.get("D4PG_PER_SAMPLE_ROLE", "1"))))
+
+    def _per_ahead(self) -> bool:
+        """Prioritised replay, no gradient exchange, a grid that leaves compute units idle: the update's priorities
+        go into the tree in extra workgroups of the critic's weight-gradient launch, and the workgroups of the
+        actor-phase launch that make the online critic's forward pass for the next update draw its rows themselves
+        (instead of a tree update beside the actor phase, a sampling role in the update's last launch and a
+        critic phase that makes its own forward pass).  ``D4PG_PER_AHEAD=0`` keeps the older scheme."""
+        return (self.supports_per_ahead and self._per_sampling_rides_along()
+                and self.B // (self.rows_per_tile_unit * self.mt) <= 128
+                and bool(int(os.environ.get("D4PG_PER_AHEAD", "1"))) and bool(int(os.environ.get("D4PG_CRITIC_AHEAD", "1"))))
 
     def _write_dev_state(self, *args, **kw) -> None:
         super()._write_dev_state(*args, **kw)
@@ -254,9 +267,10 @@ class HipCoreBf16(HipCore):
             L.ks, L.ntiles, L.N = sh.b_ld // 32, sh.b_rows // 16, sh.b_c1 - sh.b_c0
         return L
 
-    def _wgrad(self, triples, opt=None, sample_next: bool = False) -> None:
+    def _wgrad(self, triples, opt=None, sample_next: bool = False, tree_update=None) -> None:
         """dW/db of up to three layers in one launch.  ``opt=(lr, finish)`` additionally applies
         Adam + Polyak + the shadow refresh inside the same kernel (no data parallelism only)."""
+        assert tree_update is None, "the priority write-back rides in the fp32 pipeline's launch only"
         g = H.WgradGroup()
         for i, (dyT, xT, slot, sh) in enumerate(triples):
             d = g.p[i]
@@ -331,6 +345,12 @@ class HipCoreBf16(HipCore):
             return a
 
         per_role = source == "replay" and fuse_opt and self._per_sampling_rides_along()
+        per_ahead = per_role and self._per_ahead()
+        tree_dev = None
+        if per_ahead:        # the tree update's arguments in device memory, for the role in the weight-gradient launch
+            targs = self.replay.priority_update_args(self.idx, self.prio, self.B)
+            tree_dev = (torch.frombuffer(bytearray(bytes(targs)), dtype=torch.uint8).to(self.device), int(targs.parts))
+            self._tree_dev = tree_dev      # (kept alive with the segments)
 
         def seg_critic() -> None:
             if source == "replay" and not per_role:
@@ -372,13 +392,13 @@ class HipCoreBf16(HipCore):
             if self.g_pi is not None:
                 f.g_pi = self.g_pi.data_ptr()
             ah = a.ahead
-            ah.mode = self.direct_ahead.get(source, 0)
+            ah.mode = 3 if per_ahead else self.direct_ahead.get(source, 0)
             ah.h1, ah.h2, ah.lg = self.gc_h1.data_ptr(), self.gc_h2.data_ptr(), self.gc_lg.data_ptr()
             H._check(getattr(H.lib(), self._fn_critic)(a, self.mt, H.stream_ptr()), self._fn_critic)
             # the priority write-back rides along with the actor phase (seg_actor)
             self._wgrad([(self.c_dlT, self.c_h2T, cl[2], sl.critic[2]), (self.c_dh2T, self.c_h1T, cl[1], sl.critic[1]),
                          (self.c_dh1T, self.saT, cl[0], sl.critic[0])],
-                        opt=(self.lr_critic, False) if fuse_opt else None)
+                        opt=(self.lr_critic, False) if fuse_opt else None, tree_update=tree_dev)
 
         def seg_actor() -> None:
             if not fuse_opt:
@@ -397,7 +417,7 @@ class HipCoreBf16(HipCore):
             a.ab2 = self._lw(SP, sl.actor[1], P, al[1], back=True)
             a.daT, a.dh2T, a.dh1T = self.a_daT.data_ptr(), self.a_dh2T.data_ptr(), self.a_dh1T.data_ptr()
             a.q_val = self.q_val.data_ptr()
-            if source == "replay" and self.replay.prioritized:
+            if source == "replay" and self.replay.prioritized and not per_ahead:
                 a.tree = self.replay.priority_update_args(self.idx, self.prio, self.B)
             elif source in self.packed_unpack and self.packed_prio is not None:
                 a.tree = self.packed_prio      # this rank's rows of the global batch
@@ -407,10 +427,17 @@ class HipCoreBf16(HipCore):
                 ah = a.ahead
                 ah.mode = self.direct_ahead[source]
                 ah.h1, ah.h2, ah.lg = self.gc_h1.data_ptr(), self.gc_h2.data_ptr(), self.gc_lg.data_ptr()
+            elif per_ahead:      # ... and with prioritised replay its workgroups draw the next batch first
+                a.pk.enabled, a.pk.st = 0, st
+                a.smp = self._smp_dev.data_ptr()
+                a.c_saT, a.c_h1T, a.c_h2T = self.saT.data_ptr(), self.c_h1T.data_ptr(), self.c_h2T.data_ptr()
+                ah = a.ahead
+                ah.mode = 3
+                ah.h1, ah.h2, ah.lg = self.gc_h1.data_ptr(), self.gc_h2.data_ptr(), self.gc_lg.data_ptr()
             H._check(getattr(H.lib(), self._fn_actor)(a, self.mt, H.stream_ptr()), self._fn_actor)
             self._wgrad([(self.a_daT, self.a_h2T, al[2], sl.actor[2]), (self.a_dh2T, self.a_h1T, al[1], sl.actor[1]),
                          (self.a_dh1T, self.sT, al[0], sl.actor[0])],
-                        opt=(self.lr_actor, True) if fuse_opt else None, sample_next=per_role)
+                        opt=(self.lr_actor, True) if fuse_opt else None, sample_next=per_role and not per_ahead)
 
         def seg_finish() -> None:
             if not fuse_opt:

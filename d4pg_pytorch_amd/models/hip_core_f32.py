@@ -39,6 +39,7 @@ class HipCoreF32(HipCoreBf16):
     _actor_args_cls = H.ActorPhaseArgs32
     _fn_critic, _fn_actor = "d4pg_critic_phase32", "d4pg_actor_phase32"
     rows_per_tile_unit = 4
+    supports_per_ahead = True
 
     def __init__(self, cfg: Dict, device="cuda", seed: Optional[int] = None):
         HipCore.__init__(self, cfg, device, seed)
@@ -122,7 +123,7 @@ class HipCoreF32(HipCoreBf16):
         L.kg = (p.K + 3) // 4 if p.ksplit == 1 else p.nch * 8       # 16-byte k-groups that hold weights
         return L
 
-    def _wgrad(self, triples, opt=None, sample_next: bool = False) -> None:
+    def _wgrad(self, triples, opt=None, sample_next: bool = False, tree_update=None) -> None:
         g = H.WgradGroup32()
         for i, (dyT, xT, slot, sh) in enumerate(triples):
             d = g.p[i]
@@ -152,6 +153,8 @@ class HipCoreF32(HipCoreBf16):
             o.finish_step = 1 if finish else 0
         if sample_next:
             g.smp, g.smp_rows = self._smp_dev.data_ptr(), self.B
+        if tree_update is not None:        # (arguments in device memory, workgroups): the priority write-back rides along
+            g.tree, g.tree_parts = tree_update[0].data_ptr(), tree_update[1]
         H._check(H.lib().d4pg_wgrad32(g, H.stream_ptr()), "d4pg_wgrad32")
 
     def _shadow_args(self, net, slots, base: int) -> H.ShadowArgs:

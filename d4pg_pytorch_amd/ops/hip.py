@@ -244,7 +244,7 @@ class ActorPhaseArgs32(C.Structure):
                 ("cb3", LayerW32), ("cb2", LayerW32), ("cb1", LayerW32), ("ab3", LayerW32), ("ab2", LayerW32),
                 ("daT", vp), ("dh2T", vp), ("dh1T", vp), ("q_val", vp),
                 ("tree", TreeUpdateArgs), ("pk", PackedIn), ("c_saT", vp), ("c_h1T", vp), ("c_h2T", vp),
-                ("ahead", CriticAhead)]
+                ("ahead", CriticAhead), ("smp", vp)]
 
 
 class WgradDesc32(C.Structure):
@@ -257,7 +257,8 @@ class WgradDesc32(C.Structure):
 
 class WgradGroup32(C.Structure):
     _fields_ = [("p", WgradDesc32 * 3), ("count", C.c_int), ("total_tiles", C.c_int), ("Bp", C.c_int),
-                ("pad_", C.c_int), ("opt", WgradAdam), ("smp", vp), ("smp_rows", C.c_int), ("pad2_", C.c_int)]
+                ("pad_", C.c_int), ("opt", WgradAdam), ("smp", vp), ("smp_rows", C.c_int), ("tree_parts", C.c_int),
+                ("tree", vp)]
 
 
 class ActorInferArgs32(C.Structure):
