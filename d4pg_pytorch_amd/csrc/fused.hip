@@ -22,6 +22,7 @@
 // The kernel is bound by streaming those shadows from L2 (~1.4 MB per workgroup and
 // phase), not by MFMA issue, and its time is independent of the batch size until
 // B / (16*MT) exceeds the 256 CUs.
+#include <cstddef>
 #include "common.h"
 #include "loss_dev.h"
 #include "replay_dev.h"
@@ -936,7 +937,12 @@ __global__ __launch_bounds__(64 * NW) void actor_phase_kernel(const ActorPhaseAr
         return;
     }
     if (row0 >= d.B) {         // the extra workgroup
-        tree_update_body<NW>(a.tree, (int)blockIdx.x - d.B / M, (int*)smem);
+        // The tree descriptor is read IN PLACE from the kernel-argument segment: its level arrays are indexed at
+        // run time, and through the by-value parameter that makes the compiler copy the arguments to scratch
+        // memory (and every phase role of this kernel pays for the registers and the copy).
+        const TreeUpdateArgs& tree = *(const TreeUpdateArgs*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() +
+                                                              offsetof(ActorPhaseArgs, tree));
+        tree_update_body<NW>(tree, (int)blockIdx.x - d.B / M, smem, 4 * M * d.ldh * 2);      // (the hidden tiles alone)
         return;
     }
     STAMP(1, 31);
@@ -1232,7 +1238,9 @@ struct WgradGroup {
     // arguments: the tree descent indexes the level arrays of the descriptor at run time.
     const SampleArgs* smp;     // null: none
     int smp_rows;              // = smp->B (host copy: smp points to device memory)
-    int pad2_;
+    int tree_parts;            // > 0: that many more workgroups (the last of the grid) write the update's priorities
+    const TreeUpdateArgs* tree;   // into the tree (the critic's launch: the chip has idle CUs there, and the tree is
+                                  // complete before the actor phase starts); in device memory like smp
 };
 
 // NWV waves split the batch (K), then all of them finish the tile (sum of the NWV partial
@@ -1246,6 +1254,10 @@ __global__ __launch_bounds__(64 * NWV) void wgrad_kernel(const WgradGroup g) {
     float* cs = wg_smem + NWV * 16 * 64;       // [NWV][32] partial row sums
     const int total = g.total_tiles;
     const int id = blockIdx.x;
+    if (g.tree_parts > 0 && id >= (int)gridDim.x - g.tree_parts) {      // the last workgroups: priorities into the tree
+        tree_update_body<NWV>(*g.tree, id - ((int)gridDim.x - g.tree_parts), wg_smem, NWV * (16 * 64 + 32) * 4);
+        return;
+    }
     if (id == total) {          // the extra workgroup of a finishing launch
         wgrad_finish_role<NWV>(g.opt, cs);
         return;
@@ -1416,6 +1428,8 @@ static int launch_wgrad(K kernel, int nwv, int grid, const WgradGroup& g, hipStr
         if (!extra || g.smp_rows < 1) return -5;          // only behind the finish workgroup
         extra += (g.smp_rows + nwv - 1) / nwv;
     }
+    if (g.tree_parts < 0 || g.tree_parts > 64 || (g.tree_parts > 0 && g.tree == nullptr)) return -6;
+    extra += g.tree_parts;
     hipLaunchKernelGGL(kernel, dim3(grid + extra), dim3(64 * nwv), lds, stream, g);
     return (int)hipGetLastError();
 }

@@ -678,7 +678,7 @@ __global__ __launch_bounds__(64 * NW32) void actor_phase32_kernel(const ActorPha
         return;
     }
     if (row0 >= d.B) {         // the extra workgroups: priorities back into the tree
-        tree_update_body<NW32>(a.tree, (int)blockIdx.x - d.B / M, (int*)smem);
+        tree_update_body<NW32>(a.tree, (int)blockIdx.x - d.B / M, smem, 4 * M * d.ldh * 4);    // (the hidden tiles alone)
         return;
     }
     STAMP(1, 31);
@@ -1062,7 +1062,7 @@ __global__ __launch_bounds__(64 * NWV) void wgrad32_kernel(const WgradGroup32 g)
     const int total = g.total_tiles;
     const int id = blockIdx.x;
     if (g.tree_parts > 0 && id >= (int)gridDim.x - g.tree_parts) {      // the last workgroups: priorities into the tree
-        tree_update_body<NWV>(*g.tree, id - ((int)gridDim.x - g.tree_parts), (int*)wg_smem);
+        tree_update_body<NWV>(*g.tree, id - ((int)gridDim.x - g.tree_parts), wg_smem, NWV * (16 * 64 + 32) * 4);
         return;
     }
     if (id == total) {          // the extra workgroup of a finishing launch

@@ -72,9 +72,12 @@ D4PG_API int d4pg_replay_insert(const InsertArgs* a, hipStream_t stream) {
 // Tree update as a stand-alone launch (one workgroup of 16 waves); the body lives in
 // replay_dev.h because the fused bf16 pipeline runs it as an extra workgroup of its actor
 // phase kernel.
-__global__ __launch_bounds__(1024) void tree_update_kernel(const TreeUpdateArgs a) {
-    __shared__ int flag;
-    tree_update_body<16>(a, blockIdx.x, &flag);
+__global__ __launch_bounds__(1024) void tree_update_kernel(const TreeUpdateArgs, int lds_bytes) {
+    extern __shared__ __attribute__((aligned(16))) char tree_lds[];
+    // (read in place from the kernel-argument segment: the level arrays are indexed at run time, which through a
+    // by-value parameter means a copy of the arguments in scratch memory; the struct is the first parameter)
+    const TreeUpdateArgs& a = *(const TreeUpdateArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    tree_update_body<16>(a, blockIdx.x, tree_lds, lds_bytes);
 }
 
 // parts > 1 (several workgroups, csrc/replay_dev.h) needs a tree of at least three levels and the ticket counter
@@ -85,7 +88,10 @@ D4PG_API int d4pg_tree_update_check(const TreeUpdateArgs* a) {
 }
 D4PG_API int d4pg_tree_update(const TreeUpdateArgs* a, hipStream_t stream) {
     if (int rc = d4pg_tree_update_check(a)) return rc;
-    hipLaunchKernelGGL(tree_update_kernel, dim3(a->parts > 1 ? a->parts : 1), dim3(1024), 0, stream, *a);
+    // LDS for the list of owned items where it fits the default limit, else the body filters at every level
+    int lds = tree_update_lds_bytes(a->n);
+    if (lds > 64 * 1024) lds = 16;
+    hipLaunchKernelGGL(tree_update_kernel, dim3(a->parts > 1 ? a->parts : 1), dim3(1024), lds, stream, *a, lds);
     return (int)hipGetLastError();
 }
 

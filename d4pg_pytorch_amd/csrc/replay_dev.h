@@ -65,44 +65,121 @@ struct TreeUpdateArgs {
     int pad_;
 };
 
+// LDS the body needs to hold the items a workgroup owns (worst case all n of them): a counter, then per item its
+// slot (8 bytes) and its priority^alpha (4 bytes).
+__host__ __device__ __forceinline__ int tree_update_lds_bytes(int n) { return 16 + ((n + 1) & ~1) * 12; }
+
+// One node of level l >= 1 recomputed from its 64 children (contiguous: 256 B of leaves, or 512 B of fp64 sums
+// + 256 B of minima), fetched with 16-byte loads that are all in flight together.  `coherent`: the children
+// were written by other workgroups of this launch (other CUs), read them past this CU's vector cache.
+__device__ __forceinline__ void tree_recompute_node(const TreeDesc& t, int l, long long g, bool coherent) {
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    double s = 0.0;
+    float m = INFINITY;
+    if (l == 1) {
+        const f32x4* c = reinterpret_cast<const f32x4*>(t.leaf + g * 64);
+        f32x4 v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = c[k];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s += (double)v[k][e];
+                m = fminf(m, v[k][e] > 0.f ? v[k][e] : INFINITY);
+            }
+        }
+    } else if (coherent) {
+        const double* cs = t.sum[l - 1] + g * 64;
+        const float* cm = t.mn[l - 1] + g * 64;
+        for (int k = 0; k < 64; ++k) {
+            s += __hip_atomic_load(cs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            m = fminf(m, __hip_atomic_load(cm + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+    } else {
+        const f64x2* cs = reinterpret_cast<const f64x2*>(t.sum[l - 1] + g * 64);
+        const f32x4* cm = reinterpret_cast<const f32x4*>(t.mn[l - 1] + g * 64);
+        f32x4 mv[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) mv[k] = cm[k];
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) {
+            const f64x2 v = cs[k];
+            s += v[0];
+            s += v[1];
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) m = fminf(fminf(m, fminf(mv[k][0], mv[k][1])), fminf(mv[k][2], mv[k][3]));
+    }
+    t.sum[l][g] = s;
+    t.mn[l][g] = m;
+}
+
 // NWAVES = waves of the calling workgroup (all of them must call this); part = 0 .. a.parts - 1;
-// flag = one int of LDS.  Returns true (to every thread) in the workgroup that leaves the tree complete:
-// the only one, or the last to finish of several.
+// lds = tree_update_lds_bytes(a.n) bytes of LDS, 8-byte aligned (lds_bytes = what is there: with less, the items
+// are filtered again at every level instead of once).  Returns true (to every thread) in the workgroup that
+// leaves the tree complete: the only one, or the last to finish of several.
+//
+// The workgroup first COMPACTS the items it owns into LDS (slot, priority^alpha): the loads of the index list
+// are independent and pipeline, and afterwards item j of the list belongs to thread j % threads, so a level
+// costs one memory round trip however the owned items were spread over the batch (filtering the batch again
+// at every level made a thread with three owned items pay three dependent round trips per level, and every
+// thread one load of its item's index per level on top: 70 us for 4096 items in 8 workgroups, 10M rows).
 template <int NWAVES>
-__device__ __forceinline__ bool tree_update_body(const TreeUpdateArgs& a, int part, int* flag) {
+__device__ __forceinline__ bool tree_update_body(const TreeUpdateArgs& a, int part, void* lds, int lds_bytes) {
     const int tid = threadIdx.x, lane = tid & 63;
+    constexpr int nthreads = 64 * NWAVES;
     const int W = a.parts > 1 ? a.parts : 1;
     const int L = a.t.L;
     const int top_shift = 6 * (L > 1 ? L - 1 : 0);
     auto mine = [&](long long node, int level) {          // level <= L-1
         return W == 1 || (int)((node >> (top_shift - 6 * level)) % W) == part;
     };
-    // The slot of a thread's first item stays in a register: every level below would otherwise start with a
-    // load of it (the stores in between may alias) ahead of the loads of the children, two memory round trips
-    // per level instead of one.
-    const long long slot0 = tid < a.n ? a.idx[tid] : 0;
-    auto slot_of = [&](int i) { return i == tid ? slot0 : a.idx[i]; };
+    int* cnt = reinterpret_cast<int*>(lds);               // [0] items owned, [1] last-arriver flag
+    long long* l_slot = reinterpret_cast<long long*>((char*)lds + 16);
+    float* l_leaf = reinterpret_cast<float*>((char*)lds + 16 + (size_t)((a.n + 1) & ~1) * 8);
+    const bool listed = lds_bytes >= tree_update_lds_bytes(a.n);
+    if (tid == 0) cnt[0] = 0;
+    __syncthreads();
     float local_max = 0.f;
-    for (int i = tid; i < a.n; i += 64 * NWAVES) {
-        const long long slot = slot_of(i);
-        if (!mine(slot, 0)) continue;
-        float p = a.prio[i];
-        if (!(p > 0.f) || p > 3.0e38f) p = 1e-4f;   // NaN / inf / non-positive never enter the tree
-        a.t.leaf[slot] = powf(p, a.alpha);
-        local_max = fmaxf(local_max, p);
+    // four items per thread and trip: all eight loads are issued before the first is used (one memory round
+    // trip per trip; an item's priority is loaded whether the workgroup owns it or not)
+    for (int i0 = tid; i0 < a.n; i0 += 4 * nthreads) {
+        long long sl[4];
+        float pr[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + k * nthreads;
+            sl[k] = i < a.n ? a.idx[i] : -1;
+            pr[k] = i < a.n ? a.prio[i] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (sl[k] < 0 || !mine(sl[k], 0)) continue;
+            float p = pr[k];
+            if (!(p > 0.f) || p > 3.0e38f) p = 1e-4f;   // NaN / inf / non-positive never enter the tree
+            local_max = fmaxf(local_max, p);
+            const float leaf = powf(p, a.alpha);
+            if (listed) {
+                const int pos = atomicAdd(&cnt[0], 1);
+                l_slot[pos] = sl[k];
+                l_leaf[pos] = leaf;
+            } else {
+                a.t.leaf[sl[k]] = leaf;
+            }
+        }
     }
     local_max = wave_max(local_max);
     // positive floats order like their bit patterns
     if (lane == 0 && local_max > 0.f)
         atomicMax(reinterpret_cast<unsigned int*>(&a.st->max_priority), __float_as_uint(local_max));
     __syncthreads();
-    // One THREAD per touched parent: its 64 children are contiguous (256 B of leaves, or 512 B of
-    // fp64 sums + 256 B of minima), so a thread fetches them with 16-byte loads that are all in
-    // flight together and reduces them in registers; a level costs one memory round trip for the
-    // whole batch.  (Duplicate parents are recomputed to the same value.)  A level with far fewer
-    // nodes than the batch has items is recomputed whole (the top level: 4 nodes for 1M rows).
-    typedef double f64x2 __attribute__((ext_vector_type(2)));
-    const int nthreads = 64 * NWAVES;
+    const int m = listed ? cnt[0] : a.n;
+    if (listed)
+        for (int j = tid; j < m; j += nthreads) a.t.leaf[l_slot[j]] = l_leaf[j];
+    __syncthreads();
+    // One THREAD per touched parent (duplicate parents are recomputed to the same value).  A level with far
+    // fewer nodes than the batch has items is recomputed whole (the top level: 4 nodes for 1M rows).
     for (int l = 1; l <= L; ++l) {
         const long long nodes = a.t.n[l - 1] >> 6;       // nodes of this level that have children (levels are padded)
         const bool top = l == L && W > 1;
@@ -112,59 +189,27 @@ __device__ __forceinline__ bool tree_update_body(const TreeUpdateArgs& a, int pa
             __syncthreads();
             if (tid == 0) {
                 const unsigned int t = atomicAdd(a.ticket, 1u);
-                *flag = t == (unsigned int)(W - 1);
-                if (*flag) *a.ticket = 0u;             // ready for the next update (stream order)
+                cnt[1] = t == (unsigned int)(W - 1);
+                if (cnt[1]) *a.ticket = 0u;            // ready for the next update (stream order)
             }
             __syncthreads();
-            if (!*flag) return false;
+            if (!cnt[1]) return false;
             __threadfence();
         }
         const bool whole = top || nodes * 8 <= (long long)a.n;
-        const int tasks = whole ? (int)nodes : a.n;
+        const int tasks = whole ? (int)nodes : m;
         for (int i = tid; i < tasks; i += nthreads) {
-            const long long g = whole ? (long long)i : (slot_of(i) >> (6 * l));
-            if (!top && !mine(g, l)) continue;
-            double s = 0.0;
-            float m = INFINITY;
-            if (l == 1) {
-                const f32x4* c = reinterpret_cast<const f32x4*>(a.t.leaf + g * 64);
-                f32x4 v[16];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) v[k] = c[k];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        s += (double)v[k][e];
-                        m = fminf(m, v[k][e] > 0.f ? v[k][e] : INFINITY);
-                    }
-                }
-            } else if (top) {
-                // children written by other workgroups (other CUs): read past this CU's vector cache
-                const double* cs = a.t.sum[l - 1] + g * 64;
-                const float* cm = a.t.mn[l - 1] + g * 64;
-                for (int k = 0; k < 64; ++k) {
-                    s += __hip_atomic_load(cs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    m = fminf(m, __hip_atomic_load(cm + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                }
+            long long g;
+            if (whole) {
+                g = i;
+                if (!top && !mine(g, l)) continue;
+            } else if (listed) {
+                g = l_slot[i] >> (6 * l);
             } else {
-                const f64x2* cs = reinterpret_cast<const f64x2*>(a.t.sum[l - 1] + g * 64);
-                const f32x4* cm = reinterpret_cast<const f32x4*>(a.t.mn[l - 1] + g * 64);
-                f32x4 mv[16];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) mv[k] = cm[k];
-#pragma unroll 8
-                for (int k = 0; k < 32; ++k) {
-                    const f64x2 v = cs[k];
-                    s += v[0];
-                    s += v[1];
-                }
-#pragma unroll
-                for (int k = 0; k < 16; ++k)
-                    m = fminf(fminf(m, fminf(mv[k][0], mv[k][1])), fminf(mv[k][2], mv[k][3]));
+                g = a.idx[i] >> (6 * l);
+                if (!mine(g, l)) continue;
             }
-            a.t.sum[l][g] = s;
-            a.t.mn[l][g] = m;
+            tree_recompute_node(a.t, l, g, top);
         }
         __syncthreads();
     }

@@ -270,7 +270,7 @@ class HipCoreBf16(HipCore):
     def _wgrad(self, triples, opt=None, sample_next: bool = False, tree_update=None) -> None:
         """dW/db of up to three layers in one launch.  ``opt=(lr, finish)`` additionally applies
         Adam + Polyak + the shadow refresh inside the same kernel (no data parallelism only)."""
-        assert tree_update is None, "the priority write-back rides in the fp32 pipeline's launch only"
+
         g = H.WgradGroup()
         for i, (dyT, xT, slot, sh) in enumerate(triples):
             d = g.p[i]
@@ -298,6 +298,8 @@ class HipCoreBf16(HipCore):
             o.finish_step = 1 if finish else 0
         if sample_next:
             g.smp, g.smp_rows = self._smp_dev.data_ptr(), self.B
+        if tree_update is not None:        # (arguments in device memory, workgroups): the priority write-back rides along
+            g.tree, g.tree_parts = tree_update[0].data_ptr(), tree_update[1]
         H._check(H.lib().d4pg_wgrad(g, H.stream_ptr()), "d4pg_wgrad")
 
     def _segments(self, source: str):
@@ -345,9 +347,12 @@ class HipCoreBf16(HipCore):
             return a
 
         per_role = source == "replay" and fuse_opt and self._per_sampling_rides_along()
-        per_ahead = per_role and self._per_ahead()
+        per_ahead = per_role and self._per_ahead() and bool(int(os.environ.get("D4PG_TREE_IN_WGRAD", "1")))
+        # Prioritised replay with the fused optimiser: the update's priorities go into the tree in extra workgroups
+        # of the critic's weight-gradient launch (its tiles leave compute units idle at every batch size, the phase
+        # launches of a large batch do not), so the tree is complete before the actor phase starts.
         tree_dev = None
-        if per_ahead:        # the tree update's arguments in device memory, for the role in the weight-gradient launch
+        if per_role and bool(int(os.environ.get("D4PG_TREE_IN_WGRAD", "1"))):
             targs = self.replay.priority_update_args(self.idx, self.prio, self.B)
             tree_dev = (torch.frombuffer(bytearray(bytes(targs)), dtype=torch.uint8).to(self.device), int(targs.parts))
             self._tree_dev = tree_dev      # (kept alive with the segments)
@@ -417,7 +422,7 @@ class HipCoreBf16(HipCore):
             a.ab2 = self._lw(SP, sl.actor[1], P, al[1], back=True)
             a.daT, a.dh2T, a.dh1T = self.a_daT.data_ptr(), self.a_dh2T.data_ptr(), self.a_dh1T.data_ptr()
             a.q_val = self.q_val.data_ptr()
-            if source == "replay" and self.replay.prioritized and not per_ahead:
+            if source == "replay" and self.replay.prioritized and tree_dev is None:
                 a.tree = self.replay.priority_update_args(self.idx, self.prio, self.B)
             elif source in self.packed_unpack and self.packed_prio is not None:
                 a.tree = self.packed_prio      # this rank's rows of the global batch

@@ -216,7 +216,8 @@ class WgradAdam(C.Structure):
 
 class WgradGroup(C.Structure):
     _fields_ = [("p", WgradDesc * 3), ("count", C.c_int), ("total_tiles", C.c_int), ("Bp", C.c_int),
-                ("pad_", C.c_int), ("opt", WgradAdam), ("smp", vp), ("smp_rows", C.c_int), ("pad2_", C.c_int)]
+                ("pad_", C.c_int), ("opt", WgradAdam), ("smp", vp), ("smp_rows", C.c_int), ("tree_parts", C.c_int),
+                ("tree", vp)]
 
 
 # ---- fused fp32 pipeline (csrc/fused32.hip) ----
