@@ -355,10 +355,23 @@ def main() -> None:
             # both modes are timed, the one the framework's static rule (dp_mode: auto) would pick first so that
             # nothing the other run does can affect it; `value` is the faster of the two (a job is free to set
             # dp_mode), both are reported with the rule's own pick (`dp_mode_auto`)
+            import threading
             auto = resolve_dp_mode("auto", args.batch, world, args.dtype)
             runners = {"replicated": run_replicated, "grad_allreduce": run_grad_allreduce}
             other = "grad_allreduce" if auto == "replicated" else "replicated"
+            # Neither mode has ever met more than one GPU before a job like this one runs, so the first mode is
+            # bounded as well: if its collectives never complete on this machine, every rank says so and leaves
+            # with a non-zero status instead of hanging the job (nothing valid could be reported).
+            def first_mode_hung():
+                if rank == 0:
+                    print(json.dumps({"metric": "learner updates/sec", "value": None, "n_gpus": world,
+                                      "error": f"dp mode '{auto}' did not finish on {world} GPUs"}), flush=True)
+                os._exit(3)
+            first_dog = threading.Timer(float(os.environ.get("D4PG_BENCH_MODE_TIMEOUT_S", "420")), first_mode_hung)
+            first_dog.daemon = True
+            first_dog.start()
             core, dt = runners[auto]()
+            first_dog.cancel()
             metrics_primary = core.read_metrics()
             dp_mode = auto
             extra["dp_mode_auto"] = auto
@@ -368,7 +381,6 @@ def main() -> None:
             # The second mode must not cost the first its result: if it has not finished after a generous
             # multiple of the first mode's time (a collective that never completes on this machine), every rank
             # reports what it has and leaves.
-            import threading
 
             def give_up():
                 extra[other + "_error"] = "timed out"

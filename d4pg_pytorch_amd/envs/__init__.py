@@ -8,7 +8,9 @@ Resolution order for ``config['env']``:
    LunarLanderContinuous like ``env/pendulum.py:13-14`` and
    ``env/lunar_lander_continous.py:12-13``; identity otherwise)
 4. native implementation of the task (``LunarLanderContinuous-v2`` -> :class:`LunarLanderVec`, own planar
-   rigid-body simulation) or analytic stand-in of the same shape (``InvertedPendulum-v2`` -> cart-pole)
+   rigid-body simulation; ``Reacher-v2`` -> :class:`ReacherVec` and ``InvertedDoublePendulum-v2`` ->
+   :class:`InvertedDoublePendulumVec`, closed-form dynamics) or analytic stand-in of the same shape
+   (``InvertedPendulum-v2`` -> cart-pole)
 5. shape-only synthetic environment (with a warning), so that every shipped
    configuration can at least run its full pipeline.
 """
@@ -16,6 +18,7 @@ from __future__ import annotations
 
 import warnings
 
+from .analytic import InvertedDoublePendulumVec, ReacherVec
 from .base import BoxSpace, VecEnv
 from .gym_adapter import GymVec, gym_available
 from .lunar_lander import LunarLanderVec
@@ -42,6 +45,10 @@ def create_env_wrapper(config, num_envs=None, seed=None) -> VecEnv:
             warnings.warn(f"gym could not create '{name}' ({exc}); using a stand-in", stacklevel=2)
     if name.startswith("LunarLanderContinuous"):
         return LunarLanderVec(E, seed, time_limit=config["max_ep_length"], env_name=name)
+    if name.startswith("Reacher-"):
+        return ReacherVec(E, seed, time_limit=min(50, config["max_ep_length"]), env_name=name)
+    if name.startswith("InvertedDoublePendulum-"):
+        return InvertedDoublePendulumVec(E, seed, time_limit=config["max_ep_length"], env_name=name)
     if name == "InvertedPendulum-v2":
         return CartPoleContinuousVec(E, seed, time_limit=config["max_ep_length"], env_name=name)
     warnings.warn(f"no simulator for '{name}': using the shape-only synthetic environment "
@@ -51,6 +58,6 @@ def create_env_wrapper(config, num_envs=None, seed=None) -> VecEnv:
     return env
 
 
-__all__ = ["create_env_wrapper", "VecEnv", "BoxSpace", "PendulumVec", "LunarLanderVec", "SyntheticVec",
+__all__ = ["create_env_wrapper", "VecEnv", "BoxSpace", "PendulumVec", "LunarLanderVec", "ReacherVec", "InvertedDoublePendulumVec", "SyntheticVec",
            "CartPoleContinuousVec", "GymVec", "gym_available",
            "EnvWrapper", "PendulumWrapper", "LunarLanderContinous", "BipedalWalker"]
