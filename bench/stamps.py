@@ -74,6 +74,13 @@ def main():
                               "reduce_adam_stores_issued": (v[32 + 24] - v[32 + 23]) / 100.0,
                               "actor_phase_end_to_wgrad_entry": (v[32 + 20] - v[32 + 9]) / 100.0}
     if dtype != "bf16":
+        # inside two layers of the critic phase (workgroup 0, wave 0): entry -> own MFMAs ahead of the prefetch of
+        # the next layer -> prefetch issued -> tail MFMAs + epilogue -> barrier passed
+        for name, b, after, before in (("ta1_narrow", 13, 2, 1), ("ta2_hidden", 26, 3, 2)):
+            out["inside_" + name + "_last_iter"] = {
+                "barrier_to_entry": (v[b] - v[before]) / 100.0, "mfma_ahead_of_pre": (v[b + 1] - v[b]) / 100.0,
+                "pre_issue": (v[b + 2] - v[b + 1]) / 100.0, "tail_and_epilogue": (v[b + 3] - v[b + 2]) / 100.0,
+                "to_barrier_passed": (v[after] - v[b + 3]) / 100.0}
         base = v[31]      # workgroup 0 entry
         out["critic_launch_spans_last_iter_us_rel_wg0_entry"] = {
             "critic_role_first_start": (v[20] - base) / 100.0, "critic_role_last_end": (v[21] - base) / 100.0,

@@ -110,8 +110,8 @@ struct Chain32 {
     }
     // K = hidden width, N = hidden width: KSH chunks per column tile
     template <int SLOT, typename F, typename P>
-    __device__ __forceinline__ void hidden(const float* A, int lda, const LayerW32& L, F&& epi, P&& pre) {
-        layer32<NW32, MT, KSH, false>(SLOT == 0 ? t0 : t1, A, lda, L, red, epi, pre);
+    __device__ __forceinline__ void hidden(const float* A, int lda, const LayerW32& L, F&& epi, P&& pre, int lst = -1) {
+        layer32<NW32, MT, KSH, false>(SLOT == 0 ? t0 : t1, A, lda, L, red, epi, pre, lst);
     }
     // K = hidden width, N <= 64 (actions, atoms): K-slices of one column tile
     template <int SLOT, typename F, typename P>
@@ -120,8 +120,8 @@ struct Chain32 {
     }
     // K <= 32 * KSN (inputs, actions, atoms), N = hidden width
     template <int SLOT, typename F, typename P>
-    __device__ __forceinline__ void narrow(const float* A, int lda, const LayerW32& L, F&& epi, P&& pre) {
-        layer32<NW32, MT, KSN, true>(SLOT == 0 ? t0 : t1, A, lda, L, red, epi, pre);
+    __device__ __forceinline__ void narrow(const float* A, int lda, const LayerW32& L, F&& epi, P&& pre, int lst = -1) {
+        layer32<NW32, MT, KSN, true>(SLOT == 0 ? t0 : t1, A, lda, L, red, epi, pre, lst);
     }
 };
 
@@ -520,10 +520,10 @@ __global__ __launch_bounds__(64 * NW32) void critic_phase32_kernel(const CriticP
         };
     };
     // ---- target actor: s' -> a' (written into the action columns of xin2) ----
-    ch.template narrow<0>(xin2, d.ldx, a.ta[0], relu_to(bufA), [&] { ch.template prefetch_h<1>(a.ta[1]); });
+    ch.template narrow<0>(xin2, d.ldx, a.ta[0], relu_to(bufA), [&] { ch.template prefetch_h<1>(a.ta[1]); }, 13);
     __syncthreads();
     STAMP(0, 2);
-    ch.template hidden<1>(bufA, d.ldh, a.ta[1], relu_to(bufB), [&] { ch.template prefetch_s<0>(a.ta[2]); });
+    ch.template hidden<1>(bufA, d.ldh, a.ta[1], relu_to(bufB), [&] { ch.template prefetch_s<0>(a.ta[2]); }, 26);
     __syncthreads();
     STAMP(0, 3);
     ch.template split<0>(bufB, d.ldh, a.ta[2], [=](int r0, int col, f32x4 v) {

@@ -30,6 +30,18 @@
 #pragma once
 #include "common.h"
 
+// Diagnostic build (-DD4PG_STAMPS): four clock stamps inside one layer of workgroup 0 (slots lst .. lst + 3 of the
+// critic phase's row: entry, own MFMAs before `pre`, `pre` issued, tail + epilogue), for bench/stamps.py.
+#ifdef D4PG_STAMPS
+extern __device__ unsigned long long g_stamps32[2][32];
+#define LSTAMP(i)                                                                                   \
+    do {                                                                                            \
+        if (lst >= 0 && blockIdx.x == 0 && threadIdx.x == 0) g_stamps32[0][lst + (i)] = wall_clock64(); \
+    } while (0)
+#else
+#define LSTAMP(i)
+#endif
+
 constexpr int KCH = 8;                          // 16-byte k-groups per chunk (32 k)
 constexpr int CHUNK_FLOATS = KCH * 64 * 4;      // one chunk of one column tile: 8 KB
 constexpr int CHUNK_BYTES = CHUNK_FLOATS * 4;
@@ -196,7 +208,8 @@ __device__ __forceinline__ void mma_groups(const Chunk32& c, int ng, const float
 // unit only runs `pre`.
 template <int NW, int MT, int NCH, bool RT, typename F, typename P>
 __device__ __forceinline__ void layer32(Pre32& t, const float* A, int lda, const LayerW32& L, float* red, F&& epi,
-                                        P&& pre) {
+                                        P&& pre, int lst = -1) {
+    LSTAMP(0);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool split = L.ksplit > 1;
@@ -234,7 +247,9 @@ __device__ __forceinline__ void layer32(Pre32& t, const float* A, int lda, const
             }
         }
     }
+    LSTAMP(1);
     pre();
+    LSTAMP(2);
     if (has) {
         if constexpr (!RT) {
 #pragma unroll
@@ -265,4 +280,5 @@ __device__ __forceinline__ void layer32(Pre32& t, const float* A, int lda, const
         for (int r = 0; r < 4; ++r) v[r] += t.bias;
         epi(4 * mt, col, v);
     }
+    LSTAMP(3);
 }
