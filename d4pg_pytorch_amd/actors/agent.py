@@ -78,7 +78,8 @@ class Agent:
 
     # ------------------------------------------------------------------ weights
     def _try_attach_shared(self) -> None:
-        """GPU agent on the learner's device: map the learner's weight buffer (``parallel/hip_ipc.py``)."""
+        """GPU agent on the learner's machine: map the learner's weight buffer (``parallel/hip_ipc.py``), local
+        memory on the learner's own GPU, peer memory over xGMI on another one."""
         self._attach_tried = True
         if not (hasattr(self.actor, "attach_shared") and self.config.get("share_weights_ipc", True)):
             return
@@ -89,9 +90,18 @@ class Agent:
                 self._attach_tried = False           # the learner has not exported yet: look again next time
                 return
             handle, numel, dev_index = got
-            if (self.actor.device.index or 0) != dev_index:
-                return
-            self.actor.attach_shared(SharedDeviceBuffer.open(handle, numel, self.actor.device), self._half)
+            mine = self.actor.device.index or 0
+            if mine != dev_index:
+                # An agent on ANOTHER GPU of the machine maps the same buffer as peer memory: its pack kernel then
+                # reads the learner's weights over xGMI, still without a copy through the host.  Only where the
+                # runtime reports peer access between the two devices; the host slab otherwise.
+                import torch
+                if not torch.cuda.can_device_access_peer(mine, dev_index):
+                    return
+            shared = SharedDeviceBuffer.open(handle, numel, self.actor.device)
+            if mine != dev_index:
+                shared.tensor[:1].clone()            # a first read through the mapping: fails here, not in the rollout
+            self.actor.attach_shared(shared, self._half)
             self.shared_weights = True
             if self.logger is not None:
                 self.logger.scalar_summary("agent/shared_device_weights", 1.0, 0)

@@ -105,13 +105,14 @@ def test_data_parallel_wiring_on_one_gpu(dtype):
         comm.close()
 
 
-def _ipc_child(_rank, handle, numel, S, A, Hd, out_path):
+def _ipc_child(_rank, handle, numel, S, A, Hd, out_path, device="cuda:0"):
     import numpy as _np
     import torch as th
     from d4pg_pytorch_amd.actors.gpu_actor import GpuActor
     from d4pg_pytorch_amd.parallel.hip_ipc import SharedDeviceBuffer
-    shared = SharedDeviceBuffer.open(handle, numel, "cuda:0")
-    ga = GpuActor(S, A, Hd, max_batch=16)
+    th.cuda.set_device(th.device(device))
+    shared = SharedDeviceBuffer.open(handle, numel, device)
+    ga = GpuActor(S, A, Hd, max_batch=16, device=device)
     ga.attach_shared(shared, 1)                       # the target half
     x = _np.random.default_rng(0).standard_normal((16, S)).astype(_np.float32)
     outs = []
@@ -147,6 +148,35 @@ def test_hip_ipc_weights_are_read_in_place_by_another_process(tmp_path):
         cpu.load_flat(pol.flat.numpy())
         np.testing.assert_allclose(res["acts"][k].numpy(), cpu.act(x), rtol=1e-4, atol=1e-5)
     assert abs(res["sum"] - float(torch.cat([p.flat for p in pols]).double().sum())) < 1e-6
+    shared.close()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+def test_hip_ipc_weights_are_read_over_xgmi_by_an_agent_on_another_gpu(tmp_path):
+    """The same slots mapped as PEER memory by a process whose GpuActor lives on the second GPU (how an exploiter on
+    another device follows the learner without a copy through the host)."""
+    import torch.multiprocessing as mp
+    from d4pg_pytorch_amd.actors.native import CpuActor
+    from d4pg_pytorch_amd.models.nets import ActorPolicy, init_net_
+    from d4pg_pytorch_amd.parallel.hip_ipc import SharedDeviceBuffer
+    if not torch.cuda.can_device_access_peer(1, 0):
+        pytest.skip("no peer access between GPU 1 and GPU 0")
+    S, A, Hd = 24, 4, 400
+    pols = [ActorPolicy(S, A, Hd) for _ in range(4)]
+    for i, p in enumerate(pols):
+        init_net_(p.view, 0.3, torch.Generator().manual_seed(20 + i))
+    shared = SharedDeviceBuffer.create(4 * pols[0].layout.numel, "cuda:0")
+    shared.tensor.copy_(torch.cat([p.flat for p in pols]).cuda())
+    torch.cuda.synchronize()
+    out = str(tmp_path / "child.pt")
+    mp.start_processes(_ipc_child, args=(shared.handle, shared.numel, S, A, Hd, out, "cuda:1"), nprocs=1, join=True,
+                       start_method="spawn")
+    res = torch.load(out, weights_only=True)
+    x = np.random.default_rng(0).standard_normal((16, S)).astype(np.float32)
+    for k, pol in enumerate((pols[1], pols[3])):
+        cpu = CpuActor(S, A, Hd)
+        cpu.load_flat(pol.flat.numpy())
+        np.testing.assert_allclose(res["acts"][k].numpy(), cpu.act(x), rtol=1e-4, atol=1e-5)
     shared.close()
 
 
