@@ -9,8 +9,9 @@ Resolution order for ``config['env']``:
    ``env/lunar_lander_continous.py:12-13``; identity otherwise)
 4. native implementation of the task (``LunarLanderContinuous-v2`` -> :class:`LunarLanderVec`, own planar
    rigid-body simulation; ``Reacher-v2`` -> :class:`ReacherVec` and ``InvertedDoublePendulum-v2`` ->
-   :class:`InvertedDoublePendulumVec`, closed-form dynamics) or analytic stand-in of the same shape
-   (``InvertedPendulum-v2`` -> cart-pole)
+   :class:`InvertedDoublePendulumVec`, closed-form dynamics; ``BipedalWalker-v2``, ``Hopper-v2``, ``Walker2d-v2``,
+   ``HalfCheetah-v2`` -> the planar articulated-body engine of ``envs/planar.py``) or analytic stand-in of the same
+   shape (``InvertedPendulum-v2`` -> cart-pole)
 5. shape-only synthetic environment (with a warning), so that every shipped
    configuration can at least run its full pipeline.
 """
@@ -23,6 +24,7 @@ from .base import BoxSpace, VecEnv
 from .gym_adapter import GymVec, gym_available
 from .lunar_lander import LunarLanderVec
 from .pendulum import PendulumVec
+from .planar import BipedalWalkerVec, HalfCheetahVec, HopperVec, Walker2dVec
 from .synthetic import CartPoleContinuousVec, SyntheticVec
 from .wrappers import BipedalWalker, EnvWrapper, LunarLanderContinous, PendulumWrapper  # noqa: E402,F401
 
@@ -49,6 +51,11 @@ def create_env_wrapper(config, num_envs=None, seed=None) -> VecEnv:
         return ReacherVec(E, seed, time_limit=min(50, config["max_ep_length"]), env_name=name)
     if name.startswith("InvertedDoublePendulum-"):
         return InvertedDoublePendulumVec(E, seed, time_limit=config["max_ep_length"], env_name=name)
+    planar = {"BipedalWalker-": BipedalWalkerVec, "Hopper-": HopperVec, "Walker2d-": Walker2dVec,
+              "HalfCheetah-": HalfCheetahVec}
+    for prefix, cls in planar.items():
+        if name.startswith(prefix) and not name.startswith("BipedalWalkerHardcore"):
+            return cls(E, seed, time_limit=config["max_ep_length"], env_name=name)
     if name == "InvertedPendulum-v2":
         return CartPoleContinuousVec(E, seed, time_limit=config["max_ep_length"], env_name=name)
     warnings.warn(f"no simulator for '{name}': using the shape-only synthetic environment "
@@ -58,6 +65,7 @@ def create_env_wrapper(config, num_envs=None, seed=None) -> VecEnv:
     return env
 
 
-__all__ = ["create_env_wrapper", "VecEnv", "BoxSpace", "PendulumVec", "LunarLanderVec", "ReacherVec", "InvertedDoublePendulumVec", "SyntheticVec",
+__all__ = ["create_env_wrapper", "VecEnv", "BoxSpace", "PendulumVec", "LunarLanderVec", "ReacherVec", "InvertedDoublePendulumVec", "BipedalWalkerVec", "HopperVec",
+           "Walker2dVec", "HalfCheetahVec", "SyntheticVec",
            "CartPoleContinuousVec", "GymVec", "gym_available",
            "EnvWrapper", "PendulumWrapper", "LunarLanderContinous", "BipedalWalker"]

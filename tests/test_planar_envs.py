@@ -1,0 +1,162 @@
+"""The planar articulated-body tasks (envs/planar.py): BipedalWalker, Hopper, Walker2d, HalfCheetah on their own
+reduced-coordinate simulator.  Box2D and MuJoCo are not installable here, so what is pinned is the mechanics
+(energy, momentum, static equilibrium on the contact springs) and the task definitions (observation layout and
+scaling, reward terms, termination rules); trajectory parity with the reference's simulators is unpinned by
+construction (``env/bipedal.py``, ``env/utils.py:15``)."""
+import copy
+
+import numpy as np
+import pytest
+
+from d4pg_pytorch_amd.config import default_config
+from d4pg_pytorch_amd.envs import BipedalWalkerVec, HalfCheetahVec, HopperVec, Walker2dVec, create_env_wrapper
+from d4pg_pytorch_amd.envs.planar import PlanarSim
+
+ALL = [(BipedalWalkerVec, "BipedalWalker-v2", 24, 4), (HopperVec, "Hopper-v2", 11, 3), (Walker2dVec, "Walker2d-v2", 17, 6),
+       (HalfCheetahVec, "HalfCheetah-v2", 17, 6)]
+
+
+@pytest.mark.parametrize("cls,name,S,A", ALL)
+def test_factory_shapes_and_determinism(cls, name, S, A):
+    cfg = default_config(env=name, model="d4pg", device="cpu", state_dim=S, action_dim=A)
+    env = create_env_wrapper(cfg, 3, seed=7)
+    assert isinstance(env, cls) and env.state_dim == S and env.action_dim == A
+    obs = env.reset()
+    assert obs.shape == (3, S) and obs.dtype == np.float32 and np.isfinite(obs).all()
+    rng = np.random.default_rng(0)
+    acts = rng.uniform(-1, 1, (12, 3, A))
+    traj = [env.step(a) for a in acts]
+    env2 = create_env_wrapper(cfg, 3, seed=7)
+    env2.reset()
+    for (o, r, d), a in zip(traj, acts):
+        o2, r2, d2 = env2.step(a)
+        assert np.array_equal(o, o2) and np.array_equal(r, r2) and np.array_equal(d, d2)
+
+
+@pytest.mark.parametrize("cls", [c for c, *_ in ALL])
+def test_free_flight_conserves_energy_and_momentum(cls):
+    """No contact, no joint friction / springs / limits, no torques: the mechanism tumbles through the air and its
+    total energy, horizontal momentum and the parabola of its centre of mass must come out of the equations."""
+    env = cls(2, seed=1)
+    model = copy.deepcopy(env.model)
+    for l in model.links:
+        l.damping = l.stiffness = l.armature = 0.0
+        l.limits = (-np.inf, np.inf)
+    sim = PlanarSim(model, 2)
+    rng = np.random.default_rng(3)
+    sim.q[:] = rng.uniform(-0.5, 0.5, sim.q.shape)
+    sim.q[:, 1] += 20.0
+    sim.qd[:] = rng.standard_normal(sim.qd.shape) * 2.0
+    mass = sum(l.mass for l in model.links)
+
+    def momentum_x(s):
+        ang, org = s.frames()
+        px = np.zeros(2)
+        for i, l in enumerate(model.links):
+            p = s._world(ang[:, i], org[:, i], l.com)
+            px += l.mass * np.einsum("ei,ei->e", s._jacobian(i, p, org)[:, 0, :], s.qd)
+        return px
+    e0, p0 = sim.energy(), momentum_x(sim)
+    sim.step(lambda s: np.zeros((2, len(model.links))), 0.4, 800)
+    np.testing.assert_allclose(sim.energy(), e0, rtol=2e-3)
+    np.testing.assert_allclose(momentum_x(sim), p0, rtol=1e-3, atol=1e-3 * mass)       # first-order integrator: drift, not a bias
+    assert not sim.contact_on.any()
+
+
+def test_hopper_stands_on_its_contact_springs_then_falls():
+    env = HopperVec(4, seed=2)
+    obs = env.reset()
+    weight = sum(l.mass for l in env.model.links) * env.model.gravity
+    total = np.zeros(4)
+    steps = np.zeros(4, int)
+    fell_at = np.full(4, -1)
+    for t in range(400):
+        obs, r, d = env.step(np.zeros((4, 3)))
+        total += np.where(fell_at < 0, r, 0.0)
+        if t == 10:
+            # both foot contacts carry the weight: the foot sinks into the springs by about weight / (2 k), no more
+            ang, org = env.sim.frames()
+            foot = len(env.model.links) - 1
+            ys = [env.sim._world(ang[:, foot], org[:, foot], p)[:, 1] for p in ((-0.13, -0.06), (0.26, -0.06))]
+            assert all((-3 * weight / env.model.k_contact < y).all() and (y < 0.002).all() for y in ys)
+            assert env.sim.contact_on[:, :2].all() and (np.abs(env.sim.q[:, 2]) < 0.05).all()
+        for e in np.nonzero(d)[0]:
+            if fell_at[e] < 0:
+                fell_at[e] = t
+            obs[e] = env.reset_env(e)
+    # an unactuated hopper is an inverted pendulum: it stays up for a while (alive bonus 1 per step), then falls
+    assert (fell_at > 30).all() and (fell_at < 399).all()
+    np.testing.assert_allclose(total, fell_at + 1, rtol=0.15)
+
+
+def test_hopper_reward_and_termination_rules():
+    env = HopperVec(2, seed=3)
+    env.reset()
+    x0 = env.sim.q[:, 0].copy()
+    a = np.array([[0.5, -0.5, 0.25], [0.0, 0.0, 0.0]])
+    obs, r, d = env.step(a)
+    speed = (env.sim.q[:, 0] - x0) / env.DT
+    np.testing.assert_allclose(r, 1.0 + speed - 1e-3 * np.square(a).sum(1), rtol=1e-5, atol=1e-6)       # alive + forward speed - control cost
+    np.testing.assert_allclose(obs[:, :5], env.sim.q[:, 1:6], rtol=1e-6)                       # qpos[1:]: height, pitch, joints
+    np.testing.assert_allclose(obs[:, 5:], np.clip(env.sim.qd, -10, 10), rtol=1e-5, atol=1e-6)
+    assert not d.any()
+    env.sim.q[0, 2] = 0.3                              # pitched over: unhealthy
+    env.sim.q[1, 1] = 0.4                              # too low: unhealthy
+    _, _, d = env.step(np.zeros((2, 3)))
+    assert d.all()
+
+
+def test_walker_and_cheetah_rules():
+    w = Walker2dVec(2, seed=4)
+    w.reset()
+    w.sim.q[0, 2] = 1.2
+    _, _, d = w.step(np.zeros((2, 6)))
+    assert d[0] and not d[1]
+    c = HalfCheetahVec(2, seed=5, time_limit=30)
+    c.reset()
+    rng = np.random.default_rng(0)
+    for t in range(30):
+        x0 = c.sim.q[:, 0].copy()
+        a = rng.uniform(-1, 1, (2, 6))
+        obs, r, d = c.step(a)
+        np.testing.assert_allclose(r, (c.sim.q[:, 0] - x0) / c.DT - 0.1 * np.square(a).sum(1), rtol=1e-5, atol=1e-6)
+        assert np.isfinite(obs).all() and d.all() == (t == 29)                              # no termination but the limit
+    assert (c.sim.q[:, 1] > 0.2).all()                                                      # joint springs hold it off the ground
+
+
+def test_bipedal_walker_observation_reward_and_terminals():
+    env = BipedalWalkerVec(3, seed=6)
+    obs = env.reset().astype(np.float64)
+    q = env.sim.q
+    np.testing.assert_allclose(obs[:, 0], q[:, 2], atol=1e-7)                                 # hull angle
+    np.testing.assert_allclose(obs[:, 4], q[:, 3], atol=1e-7)                                 # hip 1
+    np.testing.assert_allclose(obs[:, 6], q[:, 4] + 1.0, atol=1e-7)                           # knee 1 (+1 like the gym task)
+    ang = 1.5 * np.arange(10) / 10
+    np.testing.assert_allclose(obs[:, 14:], np.clip(q[:, 1:2] / (np.cos(ang) * env.LIDAR_RANGE), 0, 1), rtol=1e-6)
+    assert (obs[:, 14] < obs[:, 23]).all() and (obs[:, 23] <= 1.0).all()                      # straight down is the nearest
+    x0, th0 = q[:, 0].copy(), q[:, 2].copy()
+    a = np.array([[1.0, -1.0, 0.5, 0.0]] * 3)
+    obs, r, d = env.step(a)
+    shaping = 130 * (env.sim.q[:, 0] - x0) / 30 - 5 * (np.abs(env.sim.q[:, 2]) - np.abs(th0))
+    np.testing.assert_allclose(r, shaping - 0.00035 * 80 * 2.5, rtol=1e-6, atol=1e-9)
+    assert not d.any()
+    # the servo drives each joint towards sign(a) x SPEED within its torque limit
+    assert (env.sim.qd[:, 3] > 0).all() and (env.sim.qd[:, 4] < 0).all()
+    # terminals: the hull on the ground, walking off the back of the track, reaching the far end
+    env.sim.q[0, 1], env.sim.q[0, 2] = 0.2, 1.5
+    env.sim.q[1, 0] = -0.1
+    env.sim.q[2, 0] = env.TRACK_END + 0.1
+    _, r, d = env.step(np.zeros((3, 4)))
+    assert d.all() and r[0] == -100.0 and r[1] == -100.0 and r[2] != -100.0
+    # an unactuated walker folds up and its hull hits the ground: about -100
+    env = BipedalWalkerVec(4, seed=7)
+    env.reset()
+    total = np.zeros(4)
+    done_at = np.full(4, -1)
+    for t in range(120):
+        _, r, d = env.step(np.zeros((4, 4)))
+        total += np.where(done_at < 0, r, 0.0)
+        done_at = np.where((done_at < 0) & d, t, done_at)
+        if (done_at >= 0).all():
+            break
+    assert (done_at > 5).all() and (total < -95).all() and (total > -115).all()
