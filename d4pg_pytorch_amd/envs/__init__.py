@@ -10,10 +10,10 @@ Resolution order for ``config['env']``:
 4. native implementation of the task (``LunarLanderContinuous-v2`` -> :class:`LunarLanderVec`, own planar
    rigid-body simulation; ``Reacher-v2`` -> :class:`ReacherVec` and ``InvertedDoublePendulum-v2`` ->
    :class:`InvertedDoublePendulumVec`, closed-form dynamics; ``BipedalWalker-v2``, ``Hopper-v2``, ``Walker2d-v2``,
-   ``HalfCheetah-v2`` -> the planar articulated-body engine of ``envs/planar.py``) or analytic stand-in of the same
-   shape (``InvertedPendulum-v2`` -> cart-pole)
+   ``HalfCheetah-v2`` -> the planar articulated-body engine of ``envs/planar.py``; ``Ant-v2`` -> the 3-D one of
+   ``envs/spatial.py``) or analytic stand-in of the same shape (``InvertedPendulum-v2`` -> cart-pole)
 5. shape-only synthetic environment (with a warning), so that every shipped
-   configuration can at least run its full pipeline.
+   id can at least run the full pipeline (every id the reference ships a configuration for resolves above).
 """
 from __future__ import annotations
 
@@ -25,6 +25,7 @@ from .gym_adapter import GymVec, gym_available
 from .lunar_lander import LunarLanderVec
 from .pendulum import PendulumVec
 from .planar import BipedalWalkerVec, HalfCheetahVec, HopperVec, Walker2dVec
+from .spatial import AntVec
 from .synthetic import CartPoleContinuousVec, SyntheticVec
 from .wrappers import BipedalWalker, EnvWrapper, LunarLanderContinous, PendulumWrapper  # noqa: E402,F401
 
@@ -52,7 +53,7 @@ def create_env_wrapper(config, num_envs=None, seed=None) -> VecEnv:
     if name.startswith("InvertedDoublePendulum-"):
         return InvertedDoublePendulumVec(E, seed, time_limit=config["max_ep_length"], env_name=name)
     planar = {"BipedalWalker-": BipedalWalkerVec, "Hopper-": HopperVec, "Walker2d-": Walker2dVec,
-              "HalfCheetah-": HalfCheetahVec}
+              "HalfCheetah-": HalfCheetahVec, "Ant-": AntVec}
     for prefix, cls in planar.items():
         if name.startswith(prefix) and not name.startswith("BipedalWalkerHardcore"):
             return cls(E, seed, time_limit=config["max_ep_length"], env_name=name)
@@ -66,6 +67,6 @@ def create_env_wrapper(config, num_envs=None, seed=None) -> VecEnv:
 
 
 __all__ = ["create_env_wrapper", "VecEnv", "BoxSpace", "PendulumVec", "LunarLanderVec", "ReacherVec", "InvertedDoublePendulumVec", "BipedalWalkerVec", "HopperVec",
-           "Walker2dVec", "HalfCheetahVec", "SyntheticVec",
+           "Walker2dVec", "HalfCheetahVec", "AntVec", "SyntheticVec",
            "CartPoleContinuousVec", "GymVec", "gym_available",
            "EnvWrapper", "PendulumWrapper", "LunarLanderContinous", "BipedalWalker"]

@@ -145,6 +145,6 @@ def make_device_env(cfg, num_envs: int, device, seed: int = 0):
         return DeviceCartPole(num_envs, device, seed, time_limit=limit)
     if name.startswith("LunarLanderContinuous"):
         return DeviceLunarLander(num_envs, device, seed, time_limit=limit)
-    if name.startswith(("Reacher-", "InvertedDoublePendulum-", "BipedalWalker-", "Hopper-", "Walker2d-", "HalfCheetah-")):
-        return None              # dynamics that exist on the host only (envs/analytic.py, envs/planar.py)
+    if name.startswith(("Reacher-", "InvertedDoublePendulum-", "BipedalWalker-", "Hopper-", "Walker2d-", "HalfCheetah-", "Ant-")):
+        return None              # dynamics that exist on the host only (envs/analytic.py, envs/planar.py, envs/spatial.py)
     return DeviceSynthetic(name, num_envs, cfg["state_dim"], cfg["action_dim"], device, seed, time_limit=limit)

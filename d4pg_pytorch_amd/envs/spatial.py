@@ -54,9 +54,10 @@ class Model3:
     c_contact: float = 30.0
     c_friction: float = 30.0
     mu: float = 1.0
-    k_limit: float = 200.0
-    c_limit: float = 2.0
+    k_limit: float = 2500.0
+    c_limit: float = 100.0
     depends: np.ndarray = field(default=None)     # [L, L]: link i moves with hinge k
+    levels: list = field(default=None)
 
     def __post_init__(self):
         L = len(self.links)
@@ -66,12 +67,29 @@ class Model3:
                 self.depends[i] = self.depends[l.parent]
                 self.depends[i, i] = True
         self.n = 6 + (L - 1)
+        depth = [0] * L
+        for i, l in enumerate(self.links):
+            if l.parent >= 0:
+                assert l.parent < i, "links are listed parents first"
+                depth[i] = depth[l.parent] + 1
+        # links of equal depth are advanced together: (their indices, their parents' indices) per level below the root
+        self.levels = [(np.array([i for i in range(L) if depth[i] == d]), np.array([self.links[i].parent for i in range(L) if depth[i] == d]))
+                       for d in range(1, max(depth) + 1)]
 
 
 def _skew(v: np.ndarray) -> np.ndarray:
     z = np.zeros_like(v[..., 0])
     return np.stack([np.stack([z, -v[..., 2], v[..., 1]], -1), np.stack([v[..., 2], z, -v[..., 0]], -1),
                      np.stack([-v[..., 1], v[..., 0], z], -1)], -2)
+
+
+def _cross(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """``a x b`` over the last axis (numpy's own spends most of its time rearranging axes at these sizes)."""
+    out = np.empty(np.broadcast_shapes(a.shape, b.shape))
+    out[..., 0] = a[..., 1] * b[..., 2] - a[..., 2] * b[..., 1]
+    out[..., 1] = a[..., 2] * b[..., 0] - a[..., 0] * b[..., 2]
+    out[..., 2] = a[..., 0] * b[..., 1] - a[..., 1] * b[..., 0]
+    return out
 
 
 def quat_to_matrix(q: np.ndarray) -> np.ndarray:
@@ -93,6 +111,7 @@ class SpatialSim:
         self.qj = np.zeros((self.E, L - 1))
         self.u = np.zeros((self.E, model.n))
         self.contact_force = np.zeros((self.E, len(model.contacts), 3))
+        self.implicit_contact = True
         self._K = np.stack([_skew(np.asarray(l.axis, float)) for l in model.links])          # [L, 3, 3]
         self._mass = np.array([l.mass for l in model.links])
         self._inertia = np.stack([np.asarray(l.inertia, float) for l in model.links])
@@ -104,6 +123,15 @@ class SpatialSim:
         self._hi = np.array([l.limits[1] for l in model.links[1:]])
         self._damp = np.array([l.damping for l in model.links[1:]])
         self._arm = np.array([l.armature for l in model.links[1:]])
+        self._KK = self._K @ self._K
+        self._eye = np.eye(3)
+        self._anchor = np.array([l.anchor for l in model.links], float)
+        self._axis = np.array([l.axis for l in model.links], float)
+        self._pt_link = np.concatenate([np.arange(L), self._c_link])
+        self._dep = model.depends[None, :, 1:, None].astype(float)
+        self._mass3 = np.repeat(self._mass, 3)
+        self._jd = np.arange(6, model.n)
+        self._g = np.array([0.0, 0.0, -model.gravity])
 
     # ---- kinematics -----------------------------------------------------------------------------
     def frames(self):
@@ -114,17 +142,13 @@ class SpatialSim:
         ax = np.zeros((E, L, 3))
         R[:, 0] = quat_to_matrix(self.quat)
         o[:, 0] = self.pos
-        eye = np.eye(3)
-        for i, l in enumerate(m.links):
-            if l.parent < 0:
-                continue
-            Rp = R[:, l.parent]
-            th = self.qj[:, i - 1]
-            K = self._K[i]
-            rot = eye[None] + np.sin(th)[:, None, None] * K[None] + (1 - np.cos(th))[:, None, None] * (K @ K)[None]
-            R[:, i] = Rp @ rot
-            o[:, i] = o[:, l.parent] + Rp @ np.asarray(l.anchor, float)
-            ax[:, i] = Rp @ np.asarray(l.axis, float)
+        for idx, par in m.levels:
+            Rp = R[:, par]                                                            # [E, k, 3, 3]
+            th = self.qj[:, idx - 1]
+            rot = self._eye + np.sin(th)[:, :, None, None] * self._K[idx] + (1 - np.cos(th))[:, :, None, None] * self._KK[idx]
+            R[:, idx] = Rp @ rot
+            o[:, idx] = o[:, par] + (Rp @ self._anchor[idx][None, :, :, None])[..., 0]
+            ax[:, idx] = (Rp @ self._axis[idx][None, :, :, None])[..., 0]
         return R, o, ax
 
     def _jacobians(self, pts: np.ndarray, link_of: np.ndarray, o: np.ndarray, ax: np.ndarray) -> np.ndarray:
@@ -132,9 +156,12 @@ class SpatialSim:
         E, P = pts.shape[:2]
         J = np.zeros((E, P, 3, self.m.n))
         J[:, :, 0, 0] = J[:, :, 1, 1] = J[:, :, 2, 2] = 1.0
-        J[:, :, :, 3:6] = -_skew(pts - o[:, None, 0])
+        r0 = pts - o[:, None, 0]
+        J[:, :, 0, 4], J[:, :, 0, 5] = r0[:, :, 2], -r0[:, :, 1]                      # -skew(r0)
+        J[:, :, 1, 3], J[:, :, 1, 5] = -r0[:, :, 2], r0[:, :, 0]
+        J[:, :, 2, 3], J[:, :, 2, 4] = r0[:, :, 1], -r0[:, :, 0]
         r = pts[:, :, None, :] - o[:, None, 1:, :]                                    # [E, P, L-1, 3]
-        c = np.cross(ax[:, None, 1:, :], r) * self.m.depends[link_of][None, :, 1:, None]
+        c = _cross(ax[:, None, 1:, :], r) * self.m.depends[link_of][None, :, 1:, None]
         J[:, :, :, 6:] = np.swapaxes(c, 2, 3)
         return J
 
@@ -142,46 +169,48 @@ class SpatialSim:
         """World angular velocity ``[E, L, 3]`` of every link."""
         w = np.zeros((self.E, len(self.m.links), 3))
         w[:, 0] = self.u[:, 3:6]
-        for i, l in enumerate(self.m.links):
-            if l.parent >= 0:
-                w[:, i] = w[:, l.parent] + ax[:, i] * self.u[:, 6 + i - 1, None]
+        for idx, par in self.m.levels:
+            w[:, idx] = w[:, par] + ax[:, idx] * self.u[:, 6 + idx - 1, None]
         return w
 
     # ---- dynamics ---------------------------------------------------------------------------------
-    def accelerations(self, tau: np.ndarray) -> np.ndarray:
-        """``u'`` for hinge torques ``tau [E, L-1]``."""
+    def accelerations(self, tau: np.ndarray, h: float = 0.0) -> np.ndarray:
+        """``u'`` for hinge torques ``tau [E, L-1]``.  With a step ``h > 0`` the contact spring-dampers are taken
+        implicitly in the velocity (``M + h J'CJ + h^2 J'KJ`` on the left-hand side): light links on stiff ground
+        stay stable at a step the free dynamics are happy with."""
         m, E, L = self.m, self.E, len(self.m.links)
         R, o, ax = self.frames()
         w = self.link_velocities(ax)
-        com = o + np.einsum("elij,lj->eli", R, self._com)
-        cpt = o[:, self._c_link] + np.einsum("ecij,cj->eci", R[:, self._c_link], self._c_local)
+        com = o + (R @ self._com[None, :, :, None])[..., 0]
+        cpt = o[:, self._c_link] + (R[:, self._c_link] @ self._c_local[None, :, :, None])[..., 0]
         cpt[:, :, 2] -= self._c_rad                                                   # the spheres' lowest points
         pts = np.concatenate([com, cpt], axis=1)
-        J = self._jacobians(pts, np.concatenate([np.arange(L), self._c_link]), o, ax)
+        J = self._jacobians(pts, self._pt_link, o, ax)
         Jc, Jk = J[:, :L], J[:, L:]
         Jw = np.zeros((E, L, 3, m.n))
         Jw[:, :, 0, 3] = Jw[:, :, 1, 4] = Jw[:, :, 2, 5] = 1.0
-        Jw[:, :, :, 6:] = np.swapaxes(ax[:, None, 1:, :] * m.depends[None, :, 1:, None], 2, 3)
-        Iw = R @ self._inertia[None] @ np.swapaxes(R, 2, 3)
-        M = np.einsum("l,elki,elkj->eij", self._mass, Jc, Jc) + np.einsum("elki,elkm,elmj->eij", Jw, Iw, Jw)
-        idx = np.arange(6, m.n)
-        M[:, idx, idx] += self._arm
+        Jw[:, :, :, 6:] = np.swapaxes(ax[:, None, 1:, :] * self._dep, 2, 3)
+        Iw = R @ self._inertia @ np.swapaxes(R, 2, 3)
+        Jc2 = Jc.reshape(E, 3 * L, m.n)
+        M = np.swapaxes(Jc2, 1, 2) @ (Jc2 * self._mass3[None, :, None])
+        IJ = (Iw @ Jw).reshape(E, 3 * L, m.n)
+        M += np.swapaxes(Jw.reshape(E, 3 * L, m.n), 1, 2) @ IJ
+        M[:, self._jd, self._jd] += self._arm
         # accelerations at u' = 0, down the tree
         a_o = np.zeros((E, L, 3))
         alpha = np.zeros((E, L, 3))
-        for i, l in enumerate(m.links):
-            if l.parent < 0:
-                continue
-            p = l.parent
-            r = o[:, i] - o[:, p]
-            a_o[:, i] = a_o[:, p] + np.cross(alpha[:, p], r) + np.cross(w[:, p], np.cross(w[:, p], r))
-            alpha[:, i] = alpha[:, p] + np.cross(w[:, p], ax[:, i]) * self.u[:, 6 + i - 1, None]
+        for idx, par in m.levels:
+            r = o[:, idx] - o[:, par]
+            wp = w[:, par]
+            a_o[:, idx] = a_o[:, par] + _cross(alpha[:, par], r) + _cross(wp, _cross(wp, r))
+            alpha[:, idx] = alpha[:, par] + _cross(wp, ax[:, idx]) * self.u[:, 6 + idx - 1, None]
         rc = com - o
-        a_c = a_o + np.cross(alpha, rc) + np.cross(w, np.cross(w, rc))
-        f_lin = self._mass[None, :, None] * (np.array([0.0, 0.0, -m.gravity])[None, None] - a_c)
-        Iw_w = np.einsum("elij,elj->eli", Iw, w)
-        t_rot = -(np.einsum("elij,elj->eli", Iw, alpha) + np.cross(w, Iw_w))
-        Q = np.einsum("elki,elk->ei", Jc, f_lin) + np.einsum("elki,elk->ei", Jw, t_rot)
+        a_c = a_o + _cross(alpha, rc) + _cross(w, _cross(w, rc))
+        f_lin = self._mass[None, :, None] * (self._g - a_c)
+        Iw_w = (Iw @ w[..., None])[..., 0]
+        t_rot = -((Iw @ alpha[..., None])[..., 0] + _cross(w, Iw_w))
+        Q = (np.swapaxes(Jc2, 1, 2) @ f_lin.reshape(E, 3 * L, 1))[..., 0]
+        Q += (np.swapaxes(Jw.reshape(E, 3 * L, m.n), 1, 2) @ t_rot.reshape(E, 3 * L, 1))[..., 0]
         qd = self.u[:, 6:]
         t = tau - self._damp * qd
         over, under = self.qj - self._hi, self._lo - self.qj
@@ -189,15 +218,26 @@ class SpatialSim:
         t = t + np.where(under > 0, m.k_limit * under - m.c_limit * qd, 0.0)
         Q[:, 6:] += t
         # contacts
-        v = np.einsum("ecki,ei->eck", Jk, self.u)
+        v = (Jk @ self.u[:, None, :, None])[..., 0]                                   # [E, C, 3]
         pen = -cpt[:, :, 2]
         on = pen > 0.0
-        fn = np.where(on, np.maximum(0.0, m.k_contact * pen - m.c_contact * v[:, :, 2]), 0.0)
+        fn = np.where(on, m.k_contact * pen - m.c_contact * v[:, :, 2], 0.0)
+        push = fn > 0.0
+        fn = np.where(push, fn, 0.0)
         ft = -m.c_friction * v[:, :, :2]
-        norm = np.linalg.norm(ft, axis=2)
-        ft = ft * np.minimum(1.0, m.mu * fn / np.maximum(norm, 1e-12))[:, :, None] * on[:, :, None]
+        norm = np.sqrt((ft * ft).sum(2))
+        cap = m.mu * fn
+        slide = norm > cap
+        ft = np.where(slide[:, :, None], ft * (cap / np.maximum(norm, 1e-12))[:, :, None], ft) * push[:, :, None]
         f = np.concatenate([ft, fn[:, :, None]], axis=2)
-        Q += np.einsum("ecki,eck->ei", Jk, f)
+        C = Jk.shape[1]
+        Q += (np.swapaxes(Jk.reshape(E, 3 * C, m.n), 1, 2) @ f.reshape(E, 3 * C, 1))[..., 0]
+        if h > 0.0:
+            gain = np.zeros((E, C, 3))
+            gain[:, :, :2] = (h * m.c_friction * (push & ~slide))[:, :, None]
+            gain[:, :, 2] = (h * m.c_contact + h * h * m.k_contact) * push
+            Jk2 = Jk.reshape(E, 3 * C, m.n)
+            M += np.swapaxes(Jk2, 1, 2) @ (Jk2 * gain.reshape(E, 3 * C, 1))
         self.contact_force = f
         self._contact_point, self._com_world = cpt, com
         return np.linalg.solve(M, Q[..., None])[..., 0]
@@ -205,7 +245,7 @@ class SpatialSim:
     def step(self, tau: np.ndarray, dt: float, substeps: int) -> None:
         h = dt / substeps
         for _ in range(substeps):
-            self.u = self.u + h * self.accelerations(tau)
+            self.u = self.u + h * self.accelerations(tau, h if self.implicit_contact else 0.0)
             self.pos = self.pos + h * self.u[:, :3]
             w = self.u[:, 3:6]
             q = self.quat
@@ -223,14 +263,14 @@ class SpatialSim:
         L = len(self.m.links)
         R, o, ax = self.frames()
         w = self.link_velocities(ax)
-        com = o + np.einsum("elij,lj->eli", R, self._com)
+        com = o + (R @ self._com[None, :, :, None])[..., 0]
         v = np.einsum("elki,ei->elk", self._jacobians(com, np.arange(L), o, ax), self.u)
         Iw = R @ self._inertia[None] @ np.swapaxes(R, 2, 3)
         Iw_w = np.einsum("elij,elj->eli", Iw, w)
         mass = self._mass[None, :]
         e = (0.5 * mass * (v ** 2).sum(2) + 0.5 * (w * Iw_w).sum(2) + mass * self.m.gravity * com[:, :, 2]).sum(1)
         p = (mass[:, :, None] * v).sum(1)
-        ang = (np.cross(com, mass[:, :, None] * v) + Iw_w).sum(1)
+        ang = (_cross(com, mass[:, :, None] * v) + Iw_w).sum(1)
         return e, p, ang
 
 
@@ -260,7 +300,7 @@ def _compose(parts):
 
 class AntVec(VecEnv):
     """``Ant-v2`` (111 observations, 8 actions)."""
-    DT, SUBSTEPS = 0.05, 10
+    DT, SUBSTEPS = 0.05, 5                       # sub-steps of 0.01 s: the published model's time step
     GEAR, DENSITY, RADIUS, TORSO_R = 150.0, 5.0, 0.08, 0.25
     Z_INIT, RESET_NOISE = 0.75, 0.1
     CTRL_COST, CONTACT_COST, ALIVE = 0.5, 0.5e-3, 1.0
@@ -307,7 +347,7 @@ class AntVec(VecEnv):
             return out
         f = s.contact_force
         arm = s._contact_point - s._com_world[:, s._c_link]
-        mom = np.cross(arm, f)
+        mom = _cross(arm, f)
         for c, link in enumerate(s._c_link):
             out[:, self.BODY_SLOT[link], :3] += mom[:, c]
             out[:, self.BODY_SLOT[link], 3:] += f[:, c]

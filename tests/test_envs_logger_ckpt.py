@@ -55,7 +55,7 @@ def test_factory_resolution_and_synthetic_shapes():
     assert d.any() and np.all(r == 1.0)
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
-        env = create_env_wrapper(default_config(env="Ant-v2", model="d4pg", device="cpu"), 4, seed=0)
+        env = create_env_wrapper(default_config(env="Humanoid-v2", model="d4pg", device="cpu", state_dim=111, action_dim=8), 4, seed=0)
     assert isinstance(env, SyntheticVec) and any("synthetic" in str(x.message) for x in w)
     obs = env.reset()
     nxt, r, d = env.step(env.get_random_action())

@@ -1,0 +1,139 @@
+"""The 3-D articulated-body simulator and the Ant task on it (envs/spatial.py).  MuJoCo is not installable here, so
+what is pinned is the mechanics (energy, linear and angular momentum in free flight, static equilibrium on the
+contact springs) and the task definition (observation layout, reward terms, termination rule); trajectory parity
+with the reference's simulator is unpinned by construction (``env/utils.py:15``, ``configs/ant_d4pg.yml``)."""
+import copy
+
+import numpy as np
+
+from d4pg_pytorch_amd.config import default_config
+from d4pg_pytorch_amd.envs import AntVec, create_env_wrapper
+from d4pg_pytorch_amd.envs.spatial import SpatialSim, quat_to_matrix
+
+
+def _free(model):
+    m = copy.deepcopy(model)
+    for l in m.links:
+        l.damping = l.armature = 0.0
+        l.limits = (-np.inf, np.inf)
+    return m
+
+
+def test_free_flight_conserves_energy_and_momenta():
+    """A tumbling, flailing ant in the air, no gravity: energy, linear and angular momentum stay put; with gravity
+    the energy still does and the vertical momentum falls by m g t."""
+    model = _free(AntVec(1).model)
+    rng = np.random.default_rng(0)
+    for g in (0.0, 9.81):
+        model.gravity = g
+        sim = SpatialSim(model, 3)
+        sim.pos[:, 2] = 50.0
+        q = rng.standard_normal((3, 4))
+        sim.quat[:] = q / np.linalg.norm(q, axis=1, keepdims=True)
+        sim.qj[:] = rng.uniform(-0.5, 0.5, sim.qj.shape)
+        sim.u[:] = rng.standard_normal(sim.u.shape) * 2.0
+        e0, p0, l0 = sim.energy_and_momentum()
+        sim.step(np.zeros((3, 8)), 0.2, 2000)
+        e1, p1, l1 = sim.energy_and_momentum()
+        np.testing.assert_allclose(e1, e0, rtol=1e-4)
+        mass = sim._mass.sum()
+        np.testing.assert_allclose(p1[:, :2], p0[:, :2], atol=2e-3)               # first-order integrator: drift, not a bias
+        np.testing.assert_allclose(p1[:, 2], p0[:, 2] - mass * g * 0.2, atol=2e-3)
+        if g == 0.0:
+            np.testing.assert_allclose(l1, l0, rtol=2e-3, atol=2e-3)
+        assert not sim.contact_force.any()
+
+
+def test_rotation_matches_quaternion_and_joint_axes():
+    env = AntVec(2, seed=0)
+    s = env.sim
+    s.quat[:] = (np.cos(0.3), 0.0, 0.0, np.sin(0.3))           # yaw by 0.6
+    R = quat_to_matrix(s.quat)
+    np.testing.assert_allclose(R[0] @ [1, 0, 0], [np.cos(0.6), np.sin(0.6), 0.0], atol=1e-12)
+    s.quat[:] = (1.0, 0.0, 0.0, 0.0)
+    s.qj[:] = 0.0
+    s.pos[:] = (0.0, 0.0, 1.0)
+    R, o, ax = s.frames()
+    np.testing.assert_allclose(o[0, 1], [0.2, 0.2, 1.0])        # hip 1
+    np.testing.assert_allclose(o[0, 2], [0.4, 0.4, 1.0])        # ankle 1
+    # every ankle's positive end of its range folds the shin DOWN (away from the torso plane)
+    for leg, (_, vec, _, rng_) in enumerate(env.LEGS):
+        s.qj[:] = 0.0
+        s.qj[:, 2 * leg + 1] = rng_[0] if abs(rng_[0]) > abs(rng_[1]) else rng_[1]
+        R, o, ax = s.frames()
+        tip = o[0, 2 + 2 * leg] + R[0, 2 + 2 * leg] @ (2 * np.asarray(vec))
+        assert tip[2] < 1.0 - 0.5
+    # a hip turns its leg about the vertical
+    s.qj[:] = 0.0
+    s.qj[:, 0] = 0.5
+    R, o, ax = s.frames()
+    np.testing.assert_allclose(o[0, 2, 2], 1.0)
+    np.testing.assert_allclose(o[0, 2, :2] - o[0, 1, :2], 0.2 * np.sqrt(2) * np.array([np.cos(np.pi / 4 + 0.5), np.sin(np.pi / 4 + 0.5)]), atol=1e-12)
+
+
+def test_ant_settles_on_four_feet_and_carries_its_weight():
+    env = AntVec(3, seed=1)
+    env.reset()
+    for _ in range(120):
+        obs, r, d = env.step(np.zeros((3, 8)))
+    s = env.sim
+    assert not d.any() and np.abs(s.u).max() < 0.05
+    weight = s._mass.sum() * env.model.gravity
+    np.testing.assert_allclose(s.contact_force[:, :, 2].sum(1), weight, rtol=0.02)
+    feet = [3, 6, 9, 12]
+    assert (s.contact_force[:, feet, 2] > 0.1 * weight).all()                  # all four feet share the load
+    np.testing.assert_allclose(r, 1.0, atol=0.02)                              # alive bonus, nothing else
+    # unpowered, gravity folds the ankles to the flat end of their range: the torso rests just above the ground
+    assert (s.pos[:, 2] > 0.3).all() and (s.pos[:, 2] < 0.45).all()
+
+
+def test_ant_observation_reward_and_termination():
+    cfg = default_config(env="Ant-v2", model="d4pg", device="cpu")
+    env = create_env_wrapper(cfg, 2, seed=3)
+    assert isinstance(env, AntVec) and env.state_dim == 111 and env.action_dim == 8
+    obs = env.reset()
+    s = env.sim
+    assert obs.shape == (2, 111) and obs.dtype == np.float32
+    np.testing.assert_allclose(obs[:, 0], s.pos[:, 2], rtol=1e-6)
+    np.testing.assert_allclose(obs[:, 1:5], s.quat, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(obs[:, 5:13], s.qj, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(obs[:, 13:16], s.u[:, :3], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(obs[:, 16:19], np.einsum("eji,ej->ei", quat_to_matrix(s.quat), s.u[:, 3:6]), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(obs[:, 19:27], s.u[:, 6:], rtol=1e-6, atol=1e-7)
+    assert not obs[:, 27:].any()                                               # in the air: no contact yet
+    a = np.array([[1.0, -1.0, 0.5, 0.0, 0.0, 0.0, -0.5, 1.0], [0.0] * 8])
+    for _ in range(15):
+        x0 = s.pos[:, 0].copy()
+        obs, r, d = env.step(a)
+        w = env.contact_wrenches()
+        want = (s.pos[:, 0] - x0) / env.DT + 1.0 - 0.5 * np.square(a).sum(1) - 0.5e-3 * np.square(w).sum((1, 2))
+        np.testing.assert_allclose(r, want, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(obs[:, 27:], w.reshape(2, 84), rtol=1e-6)
+    assert np.abs(obs[:, 27:]).max() == 1.0 and obs[:, 27:].any(axis=1).all()  # on the ground: clipped wrenches
+    assert not d.any()
+    s.pos[0, 2] = 1.2
+    _, _, d = env.step(np.zeros((2, 8)))
+    assert d[0] and not d[1]
+    env.reset_env(0)
+    env.HEALTHY_Z = (0.6, 1.0)                         # the lower bound, seen from a crouching ant
+    _, _, d = env.step(np.zeros((2, 8)))
+    assert d[1] and not d[0]
+
+
+def test_ant_is_deterministic_and_survives_random_torques():
+    rng = np.random.default_rng(0)
+    acts = rng.uniform(-1, 1, (150, 4, 8))
+    outs = []
+    for _ in range(2):
+        env = AntVec(4, seed=5)
+        env.reset()
+        tr = []
+        for a in acts:
+            o, r, d = env.step(a)
+            assert np.isfinite(o).all() and np.isfinite(r).all() and np.abs(o).max() < 60.0
+            for e in np.nonzero(d)[0]:
+                env.reset_env(e)
+            tr.append((o, r, d))
+        outs.append(tr)
+    for (o1, r1, d1), (o2, r2, d2) in zip(*outs):
+        assert np.array_equal(o1, o2) and np.array_equal(r1, r2) and np.array_equal(d1, d2)
