@@ -29,6 +29,10 @@ from d4pg_pytorch_amd.engine import load_engine          # noqa: E402
 from d4pg_pytorch_amd.utils.logger import read_events    # noqa: E402
 
 
+#: ids with dynamics of their own among the device kernels (everything else: shape-only dynamics)
+NATIVE_DEVICE_ENVS = ("Pendulum", "InvertedPendulum-v2", "LunarLanderContinuous", "Hopper-", "Walker2d-", "HalfCheetah-", "BipedalWalker-")
+
+
 def gpu_rollout_bench(args):
     import numpy as np
     import torch
@@ -43,7 +47,7 @@ def gpu_rollout_bench(args):
     cfg = default_config(env=args.rollout_env, model="d4pg", batch_size=256, dense_size=400, device="cuda",
                          n_step_returns=5, replay_mem_size=1_000_000, v_min=-20.0 if pend else -100.0,
                          v_max=0.0 if pend else 100.0, replay_memory_prioritized=args.per,
-                         synthetic_env=not pend and args.rollout_env != "InvertedPendulum-v2")
+                         synthetic_env=not args.rollout_env.startswith(NATIVE_DEVICE_ENVS))
     core = build_core(cfg, "cuda")
     rp = HbmReplay(cfg, "cuda", core.dev_state)
     core.attach_replay(rp)

@@ -6,6 +6,9 @@
   n-step assembly sees ``done`` flags that stop the bootstrap, not only time limits.
 * :class:`DeviceLunarLander` — ``envs/lunar_lander.py::LunarLanderVec`` (the task of ``LunarLanderContinuous-v2``:
   engines, spring-damper feet, shaped reward, crash / landing terminals), one thread per environment.
+* :class:`DevicePlanar` — ``envs/planar.py`` (Hopper, Walker2d, HalfCheetah, BipedalWalker: articulated bodies
+  with ground contact), one thread per environment, mass matrix and Cholesky solve in registers
+  (``csrc/planar_env.hip``).
 * :class:`DeviceSynthetic` — ``envs/synthetic.py::SyntheticVec`` for any observation / action shape (the same
   fixed dynamics matrices), so that the throughput configurations (Ant: 111 / 8, ...) can run their explorers
   on the GPU as well.
@@ -108,6 +111,81 @@ class DeviceLunarLander(_DeviceEnvBase):
         H.launch("d4pg_lander_step", a)
 
 
+class DevicePlanar(_DeviceEnvBase):
+    """``envs/planar.py`` (Hopper, Walker2d, HalfCheetah, BipedalWalker) on the device: the mechanism's topology
+    is compiled into ``csrc/planar_env.hip``; every number (masses, lengths, gains, task coefficients) is read
+    from the host class, so the two cannot drift apart."""
+    KINDS = {"HopperVec": 0, "Walker2dVec": 1, "HalfCheetahVec": 2, "BipedalWalkerVec": 3}
+    STRIDE = 24
+
+    def __init__(self, host_cls, num_envs: int, device="cuda", seed: int = 0, time_limit: int = 1000, limit_terminal: bool = True):
+        host = host_cls(1)
+        super().__init__(num_envs, host.state_dim, host.action_dim, device, seed, time_limit)
+        self.kind = self.KINDS[host_cls.__name__]
+        self.state = torch.zeros(self.E, self.STRIDE, dtype=torch.float32, device=self.device)
+        self.limit_terminal = bool(limit_terminal)
+        self.n = host.model.n
+        self.params = self._params(host)
+        self._params_dev = torch.frombuffer(bytearray(bytes(self.params)), dtype=torch.uint8).to(self.device)
+
+    @staticmethod
+    def _pack(values) -> int:
+        out = 0
+        for i, v in enumerate(values):
+            out |= (int(v) + 1) << (4 * i)
+        return out
+
+    def _params(self, host) -> H.PlanarParams:
+        m, p = host.model, H.PlanarParams()
+        if len(m.links) > 8 or len(m.contacts) > 8:
+            raise ValueError("planar device kernels hold at most 8 links and 8 contact points")
+        for i, l in enumerate(m.links):
+            p.anchor[i][0], p.anchor[i][1] = l.anchor
+            p.com[i][0], p.com[i][1] = l.com
+            p.mass[i], p.inertia[i], p.rest[i] = l.mass, l.inertia, l.rest
+            p.lo[i], p.hi[i] = max(l.limits[0], -1e30), min(l.limits[1], 1e30)
+            p.damping[i], p.armature[i], p.stiffness[i] = l.damping, l.armature, l.stiffness
+        for c, (link, local) in enumerate(m.contacts):
+            p.c_local[c][0], p.c_local[c][1] = local
+        p.gravity, p.k_contact, p.c_contact, p.c_friction, p.mu = m.gravity, m.k_contact, m.c_contact, m.c_friction, m.mu
+        p.k_limit, p.c_limit = m.k_limit, m.c_limit
+        p.n_links, p.n_contacts, p.n_act = len(m.links), len(m.contacts), host.action_dim
+        p.parents = self._pack(l.parent for l in m.links)
+        p.contact_links = self._pack(link for link, _ in m.contacts)
+        big = 1e30
+        if self.kind == 3:
+            p.dt, p.substeps = 1.0 / host.FPS, host.SUBSTEPS
+        else:
+            p.dt, p.substeps = host.DT, host.SUBSTEPS
+            for j, g in enumerate(host.gears):
+                p.gear[j] = g
+            p.alive, p.ctrl_cost, p.reset_noise, p.q0_y = host.ALIVE, host.CTRL_COST, host.RESET_NOISE, host.q0_y
+            # healthy: z_min <= q[1] + z_off <= z_max and |root angle| <= ang_max (the rules of _unhealthy() of each class)
+            p.z_off, p.z_min, p.z_max, p.ang_max = {0: (0.2, 0.7, big, 0.2), 1: (0.2, 0.8, 2.0, 1.0), 2: (0.0, -big, big, big)}[self.kind]
+        return p
+
+    def _args(self, init: int) -> H.PlanarEnvArgs:
+        a = H.PlanarEnvArgs()
+        self._fill(a, init)
+        a.P, a.kind = self._params_dev.data_ptr(), self.kind
+        a.limit_terminal, a.reward_scale = int(self.limit_terminal), self.reward_scale
+        return a
+
+    def _launch(self, a) -> None:
+        H._check(H.lib().d4pg_planar_env_step(H.C.byref(a), H.C.byref(self.params), H.stream_ptr(None)), "d4pg_planar_env_step")
+
+    # state hand-over with the host class (tests, warm starts)
+    def set_state(self, q: np.ndarray, qd: np.ndarray) -> None:
+        st = torch.zeros(self.E, self.STRIDE, dtype=torch.float32)
+        st[:, :self.n] = torch.as_tensor(q, dtype=torch.float32)
+        st[:, 9:9 + self.n] = torch.as_tensor(qd, dtype=torch.float32)
+        if self.kind == 3:
+            st[:, 20] = 130.0 * st[:, 0] / 30.0 - 5.0 * st[:, 2].abs()
+        self.state.copy_(st)
+        self.t.zero_()
+        self.ep_return.zero_()
+
+
 class DeviceSynthetic(_DeviceEnvBase):
     def __init__(self, env_name: str, num_envs: int, state_dim: int, action_dim: int, device="cuda", seed: int = 0,
                  time_limit: int = 1000, terminal_prob: float = 0.001, noise_std: float = 0.05):
@@ -145,6 +223,11 @@ def make_device_env(cfg, num_envs: int, device, seed: int = 0):
         return DeviceCartPole(num_envs, device, seed, time_limit=limit)
     if name.startswith("LunarLanderContinuous"):
         return DeviceLunarLander(num_envs, device, seed, time_limit=limit)
-    if name.startswith(("Reacher-", "InvertedDoublePendulum-", "BipedalWalker-", "Hopper-", "Walker2d-", "HalfCheetah-", "Ant-")):
-        return None              # dynamics that exist on the host only (envs/analytic.py, envs/planar.py, envs/spatial.py)
+    from . import planar
+    for prefix, cls in (("Hopper-", planar.HopperVec), ("Walker2d-", planar.Walker2dVec), ("HalfCheetah-", planar.HalfCheetahVec),
+                        ("BipedalWalker-", planar.BipedalWalkerVec)):
+        if name.startswith(prefix):
+            return DevicePlanar(cls, num_envs, device, seed, time_limit=limit)
+    if name.startswith(("Reacher-", "InvertedDoublePendulum-", "Ant-")):
+        return None              # dynamics that exist on the host only (envs/analytic.py, envs/spatial.py)
     return DeviceSynthetic(name, num_envs, cfg["state_dim"], cfg["action_dim"], device, seed, time_limit=limit)

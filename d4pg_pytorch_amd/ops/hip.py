@@ -299,6 +299,26 @@ class LanderArgs(C.Structure):
                 ("limit_terminal", C.c_int), ("reward_scale", C.c_float)]
 
 
+class PlanarParams(C.Structure):
+    """Numbers of a planar mechanism and its task (csrc/planar_env.hip); filled from ``envs/planar.py`` models."""
+    _f8, _f82 = C.c_float * 8, (C.c_float * 2) * 8
+    _fields_ = [("anchor", _f82), ("com", _f82), ("mass", _f8), ("inertia", _f8), ("rest", _f8), ("lo", _f8), ("hi", _f8),
+                ("damping", _f8), ("armature", _f8), ("stiffness", _f8), ("c_local", _f82), ("gear", _f8),
+                ("gravity", C.c_float), ("k_contact", C.c_float), ("c_contact", C.c_float), ("c_friction", C.c_float),
+                ("mu", C.c_float), ("k_limit", C.c_float), ("c_limit", C.c_float),
+                ("dt", C.c_float), ("alive", C.c_float), ("ctrl_cost", C.c_float), ("reset_noise", C.c_float),
+                ("q0_y", C.c_float), ("z_off", C.c_float), ("z_min", C.c_float), ("z_max", C.c_float), ("ang_max", C.c_float),
+                ("substeps", C.c_int), ("n_links", C.c_int), ("n_contacts", C.c_int), ("n_act", C.c_int),
+                ("parents", C.c_ulonglong), ("contact_links", C.c_ulonglong)]
+
+
+class PlanarEnvArgs(C.Structure):
+    _fields_ = [("P", vp), ("state", vp), ("t", vp), ("ep_return", vp), ("action", vp), ("obs", vp), ("next_obs", vp),
+                ("reward", vp), ("done", vp), ("trunc", vp), ("noise", vp), ("stats", vp), ("counter", vp),
+                ("seed", C.c_ulonglong), ("E", C.c_int), ("ld_act", C.c_int), ("time_limit", C.c_int), ("init", C.c_int),
+                ("limit_terminal", C.c_int), ("kind", C.c_int), ("reward_scale", C.c_float)]
+
+
 class SyntheticEnvArgs(C.Structure):
     _fields_ = [("state", vp), ("t", vp), ("ep_return", vp), ("M", vp), ("N", vp), ("action", vp), ("obs", vp),
                 ("next_obs", vp), ("reward", vp), ("done", vp), ("trunc", vp), ("noise", vp), ("stats", vp),
@@ -401,6 +421,7 @@ def lib() -> C.CDLL:
             ("d4pg_cartpole_step", [C.POINTER(CartPoleArgs), vp]),
             ("d4pg_synthetic_env_step", [C.POINTER(SyntheticEnvArgs), vp]),
             ("d4pg_lander_step", [C.POINTER(LanderArgs), vp]),
+            ("d4pg_planar_env_step", [C.POINTER(PlanarEnvArgs), C.POINTER(PlanarParams), vp]),
             ("d4pg_rollout_rows", [C.POINTER(RolloutRowsArgs), vp]),
             ("d4pg_ipc_alloc", [C.c_size_t, C.POINTER(vp), C.c_char_p]),
             ("d4pg_ipc_open", [C.c_char_p, C.POINTER(vp)]),

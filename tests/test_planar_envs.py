@@ -160,3 +160,67 @@ def test_bipedal_walker_observation_reward_and_terminals():
         if (done_at >= 0).all():
             break
     assert (done_at > 5).all() and (total < -95).all() and (total > -115).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cls,name,S,A", ALL)
+def test_device_planar_follows_the_host_simulator(cls, name, S, A):
+    """The device kernels (csrc/planar_env.hip, fp32) against the host simulator (fp64): ONE step from identical
+    states with identical actions, then the host follows the device.  Contacts are stiff and touch-down is a
+    threshold, so a few environments per step may disagree on a contact made within rounding."""
+    import torch
+    from d4pg_pytorch_amd.envs.device_envs import DevicePlanar, make_device_env
+    E = 256
+    limit = 120
+    cfg = default_config(env=name, model="d4pg", device="cuda", max_ep_length=limit, state_dim=S, action_dim=A)
+    dev = make_device_env(cfg, E, "cuda", seed=11)
+    assert isinstance(dev, DevicePlanar) and dev.state_dim == S and dev.action_dim == A
+    obs = torch.zeros(E, S, device="cuda")
+    dev.reset(obs)
+    torch.cuda.synchronize()
+    host = cls(E, seed=0, time_limit=limit)
+    host.reset()
+    n = host.model.n
+    st0 = dev.state.cpu().double().numpy()
+    if cls is BipedalWalkerVec:
+        assert np.all(st0[:, 0] == np.float32(host.START_X)) and st0[:, 9].std() > 0.01       # the random push
+    else:
+        assert np.abs(st0[:, 0]).max() <= host.RESET_NOISE and st0[:, :n].std() > 0.2 * host.RESET_NOISE
+
+    def follow():
+        st = dev.state.cpu().double().numpy()
+        host.sim.q[:], host.sim.qd[:] = st[:, :n], st[:, 9:9 + n]
+        host.t[:] = dev.t.cpu().numpy()
+        if cls is BipedalWalkerVec:
+            host.sim.contact_on[:] = False
+            host.sim.contact_on[:, :2] = st[:, 18:20] > 0.5
+            host.prev_shaping[:] = st[:, 20]
+    follow()
+    np.testing.assert_allclose(obs.cpu().numpy(), host._obs(), rtol=1e-5, atol=1e-6)
+    nobs, rew, done, trunc = (torch.zeros(E, S, device="cuda"), torch.zeros(E, device="cuda"),
+                              torch.zeros(E, device="cuda"), torch.zeros(E, device="cuda"))
+    g = torch.Generator().manual_seed(4)
+    ended_total, worst = 0, 1.0
+    for t in range(300):
+        act = (torch.rand(E, A, generator=g) * 2.6 - 1.3)                     # beyond [-1, 1]: clipped on both sides
+        act[: E // 4] = 0.0
+        act = act.cuda()
+        dev.step(act, obs, nobs, rew, done, trunc)
+        torch.cuda.synchronize()
+        o_h, r_h, d_h = host._step(act.cpu().numpy())
+        o_d = nobs.cpu().numpy()
+        close = np.all(np.abs(o_d - o_h) <= 5e-3 + 5e-3 * np.abs(o_h), axis=1)
+        worst = min(worst, close.mean())
+        assert close.mean() > 0.95, (t, np.abs(o_d - o_h).max(axis=1))
+        d_d = done.cpu().numpy() > 0.5
+        agree = (d_d == d_h) & close
+        assert agree.mean() > 0.95
+        np.testing.assert_allclose(rew.cpu().numpy()[agree], r_h[agree], rtol=2e-3, atol=0.05)
+        assert not trunc.any()
+        ended = torch.from_numpy(d_d).cuda()
+        ended_total += int(d_d.sum())
+        assert torch.equal(obs[~ended], nobs[~ended]) and (dev.t[ended] == 0).all()
+        follow()
+    mean_ret, count = dev.episode_stats()
+    assert count == ended_total and count >= E and np.isfinite(mean_ret)
+    assert torch.isfinite(dev.state).all()
