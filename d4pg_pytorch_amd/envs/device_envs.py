@@ -6,6 +6,7 @@
   n-step assembly sees ``done`` flags that stop the bootstrap, not only time limits.
 * :class:`DeviceLunarLander` — ``envs/lunar_lander.py::LunarLanderVec`` (the task of ``LunarLanderContinuous-v2``:
   engines, spring-damper feet, shaped reward, crash / landing terminals), one thread per environment.
+* :class:`DeviceAnalytic` — ``envs/analytic.py`` (Reacher, inverted double pendulum: closed-form dynamics).
 * :class:`DevicePlanar` — ``envs/planar.py`` (Hopper, Walker2d, HalfCheetah, BipedalWalker: articulated bodies
   with ground contact), one thread per environment, mass matrix and Cholesky solve in registers
   (``csrc/planar_env.hip``).
@@ -109,6 +110,26 @@ class DeviceLunarLander(_DeviceEnvBase):
 
     def _launch(self, a) -> None:
         H.launch("d4pg_lander_step", a)
+
+
+class DeviceAnalytic(_DeviceEnvBase):
+    """``envs/analytic.py`` on the device: ``kind`` 0 = Reacher (2 actions), 1 = inverted double pendulum (1 action);
+    11 observations each (``csrc/analytic_env.hip``)."""
+
+    def __init__(self, kind: int, num_envs: int, device="cuda", seed: int = 0, time_limit: int = 1000, limit_terminal: bool = True):
+        super().__init__(num_envs, 11, 2 if kind == 0 else 1, device, seed, time_limit)
+        self.kind = int(kind)
+        self.state = torch.zeros(self.E, 8, dtype=torch.float32, device=self.device)
+        self.limit_terminal = bool(limit_terminal)
+
+    def _args(self, init: int) -> H.AnalyticEnvArgs:
+        a = H.AnalyticEnvArgs()
+        self._fill(a, init)
+        a.kind, a.limit_terminal, a.reward_scale = self.kind, int(self.limit_terminal), self.reward_scale
+        return a
+
+    def _launch(self, a) -> None:
+        H.launch("d4pg_analytic_env_step", a)
 
 
 class DevicePlanar(_DeviceEnvBase):
@@ -228,6 +249,10 @@ def make_device_env(cfg, num_envs: int, device, seed: int = 0):
                         ("BipedalWalker-", planar.BipedalWalkerVec)):
         if name.startswith(prefix):
             return DevicePlanar(cls, num_envs, device, seed, time_limit=limit)
-    if name.startswith(("Reacher-", "InvertedDoublePendulum-", "Ant-")):
-        return None              # dynamics that exist on the host only (envs/analytic.py, envs/spatial.py)
+    if name.startswith("Reacher-"):
+        return DeviceAnalytic(0, num_envs, device, seed, time_limit=min(50, limit))
+    if name.startswith("InvertedDoublePendulum-"):
+        return DeviceAnalytic(1, num_envs, device, seed, time_limit=limit)
+    if name.startswith("Ant-"):
+        return None              # dynamics that exist on the host only (envs/spatial.py)
     return DeviceSynthetic(name, num_envs, cfg["state_dim"], cfg["action_dim"], device, seed, time_limit=limit)

@@ -319,6 +319,13 @@ class PlanarEnvArgs(C.Structure):
                 ("limit_terminal", C.c_int), ("kind", C.c_int), ("reward_scale", C.c_float)]
 
 
+class AnalyticEnvArgs(C.Structure):
+    _fields_ = [("state", vp), ("t", vp), ("ep_return", vp), ("action", vp), ("obs", vp), ("next_obs", vp),
+                ("reward", vp), ("done", vp), ("trunc", vp), ("noise", vp), ("stats", vp), ("counter", vp),
+                ("seed", C.c_ulonglong), ("E", C.c_int), ("ld_act", C.c_int), ("time_limit", C.c_int), ("init", C.c_int),
+                ("limit_terminal", C.c_int), ("kind", C.c_int), ("reward_scale", C.c_float)]
+
+
 class SyntheticEnvArgs(C.Structure):
     _fields_ = [("state", vp), ("t", vp), ("ep_return", vp), ("M", vp), ("N", vp), ("action", vp), ("obs", vp),
                 ("next_obs", vp), ("reward", vp), ("done", vp), ("trunc", vp), ("noise", vp), ("stats", vp),
@@ -422,6 +429,7 @@ def lib() -> C.CDLL:
             ("d4pg_synthetic_env_step", [C.POINTER(SyntheticEnvArgs), vp]),
             ("d4pg_lander_step", [C.POINTER(LanderArgs), vp]),
             ("d4pg_planar_env_step", [C.POINTER(PlanarEnvArgs), C.POINTER(PlanarParams), vp]),
+            ("d4pg_analytic_env_step", [C.POINTER(AnalyticEnvArgs), vp]),
             ("d4pg_rollout_rows", [C.POINTER(RolloutRowsArgs), vp]),
             ("d4pg_ipc_alloc", [C.c_size_t, C.POINTER(vp), C.c_char_p]),
             ("d4pg_ipc_open", [C.c_char_p, C.POINTER(vp)]),

@@ -128,3 +128,65 @@ def test_double_pendulum_is_balanced_by_linear_feedback():
         total += r[0]
         assert not done[0], t
     assert total / 400 > 9.2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["Reacher-v2", "InvertedDoublePendulum-v2"])
+def test_device_twins_follow_the_host_dynamics(name):
+    """csrc/analytic_env.hip (fp32) against envs/analytic.py (fp64): one step from identical states and actions,
+    then the host follows the device."""
+    import torch
+    from d4pg_pytorch_amd.envs.device_envs import DeviceAnalytic, make_device_env
+    E = 512
+    reach = name.startswith("Reacher")
+    limit = 50 if reach else 200
+    cfg = default_config(env=name, model="d4pg", device="cuda", max_ep_length=limit)
+    dev = make_device_env(cfg, E, "cuda", seed=3)
+    assert isinstance(dev, DeviceAnalytic) and dev.time_limit == limit
+    A = dev.action_dim
+    obs = torch.zeros(E, 11, device="cuda")
+    dev.reset(obs)
+    torch.cuda.synchronize()
+    host = (ReacherVec if reach else InvertedDoublePendulumVec)(E, seed=0, time_limit=limit)
+    host.reset()
+    st = dev.state.cpu().double().numpy()
+    if reach:
+        assert np.abs(st[:, :2]).max() <= 0.1 and np.abs(st[:, 2:4]).max() <= 0.005
+        rad = np.linalg.norm(st[:, 4:6], axis=1)
+        assert rad.max() <= 0.2 and 0.1 < rad.mean() < 0.16                     # uniform in the disk: mean radius 2/3 x 0.2
+    else:
+        assert np.abs(st[:, :2]).max() <= 0.1 and np.abs(st[:, 2] - st[:, 1]).max() <= 0.1 + 1e-6
+        assert 0.07 < st[:, 3:6].std() < 0.13                                   # normal deviates x 0.1
+
+    def follow():
+        st = dev.state.cpu().double().numpy()
+        if reach:
+            host.q[:], host.qd[:], host.target[:] = st[:, 0:2], st[:, 2:4], st[:, 4:6]
+        else:
+            host.q[:], host.qd[:] = st[:, 0:3], st[:, 3:6]
+        host.t[:] = dev.t.cpu().numpy()
+    follow()
+    np.testing.assert_allclose(obs.cpu().numpy(), host._obs(), rtol=1e-5, atol=1e-6)
+    nobs, rew, done, trunc = (torch.zeros(E, 11, device="cuda"), torch.zeros(E, device="cuda"),
+                              torch.zeros(E, device="cuda"), torch.zeros(E, device="cuda"))
+    g = torch.Generator().manual_seed(1)
+    ended_total = 0
+    for t in range(260):
+        act = (torch.rand(E, A, generator=g) * 2.6 - 1.3).cuda()               # beyond [-1, 1]: clipped (reacher: cost on the raw action)
+        dev.step(act, obs, nobs, rew, done, trunc)
+        torch.cuda.synchronize()
+        o_h, r_h, d_h = host._step(act.cpu().numpy())
+        np.testing.assert_allclose(nobs.cpu().numpy(), o_h, rtol=2e-3, atol=2e-3)
+        np.testing.assert_allclose(rew.cpu().numpy(), r_h, rtol=2e-3, atol=2e-3)
+        d_d = done.cpu().numpy() > 0.5
+        assert (d_d == d_h).mean() > 0.995 and not trunc.any()                 # a tip within rounding of y = 1 may differ
+        ended = torch.from_numpy(d_d).cuda()
+        ended_total += int(d_d.sum())
+        assert torch.equal(obs[~ended], nobs[~ended]) and (dev.t[ended] == 0).all()
+        follow()
+    mean_ret, count = dev.episode_stats()
+    assert count == ended_total and count >= E
+    if reach:
+        assert -120.0 < mean_ret < -20.0          # 50 steps of -|a|^2 (about 1.1 at random) - distance
+    else:
+        assert 20.0 < mean_ret < 200.0            # a few steps of about 9 before the tip drops below 1

@@ -191,6 +191,22 @@ gpu_rollout_segment: 32   # steps per captured rollout segment
 gpu_rollout_interval: 32  # learner updates between two segments (64 env steps per update)
 num_steps_train: 50000
 """,
+    "walker2d_d4pg_device_explorers.yml": """# Walker2d D4PG with the explorers ON the learner's GPU (csrc/planar_env.hip: the articulated-body simulator as a
+# kernel, one thread per environment); the GPU exploiter plays the host simulator (envs/planar.py) with the
+# learner's target policy, read through HIP IPC.  Same for Hopper-v2, HalfCheetah-v2 (v_min -50, v_max 600) and
+# BipedalWalker-v2 (v_min -100, v_max 300, max_ep_length 1600): --set env=... state_dim=... action_dim=...
+env: Walker2d-v2
+model: d4pg
+num_agents: 1             # the exploiter only
+v_min: 0.0                # the range discounted returns take (gamma 0.99, reward per step up to about 4)
+v_max: 400.0
+device: cuda
+replay_device: hbm
+gpu_rollout_envs: 256     # environments stepped on the GPU
+gpu_rollout_segment: 32   # steps per captured rollout segment
+gpu_rollout_interval: 32  # learner updates between two segments (256 env steps per update)
+num_steps_train: 200000
+""",
     "pendulum_d4pg_cpu.yml": """# Pendulum D4PG entirely on the CPU: learner + sampler + agent processes (plumbing, no GPU).
 env: Pendulum-v0
 model: d4pg
