@@ -31,7 +31,7 @@ from d4pg_pytorch_amd.utils.logger import read_events    # noqa: E402
 
 #: ids with dynamics of their own among the device kernels (everything else: shape-only dynamics)
 NATIVE_DEVICE_ENVS = ("Pendulum", "InvertedPendulum-v2", "LunarLanderContinuous", "Hopper-", "Walker2d-", "HalfCheetah-", "BipedalWalker-", "Reacher-",
-                      "InvertedDoublePendulum-")
+                      "InvertedDoublePendulum-", "Ant-")
 
 
 def gpu_rollout_bench(args):

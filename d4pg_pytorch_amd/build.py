@@ -19,7 +19,7 @@ from typing import List
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-HIP_SOURCES = ["gemm.hip", "loss.hip", "optim.hip", "replay.hip", "nstep.hip", "fused.hip", "fused32.hip", "rollout.hip", "planar_env.hip", "analytic_env.hip"]
+HIP_SOURCES = ["gemm.hip", "loss.hip", "optim.hip", "replay.hip", "nstep.hip", "fused.hip", "fused32.hip", "rollout.hip", "planar_env.hip", "analytic_env.hip", "ant_env.hip"]
 HOST_SOURCES = ["host_runtime.cpp"]
 HIP_LIB = os.path.join(CSRC, "libd4pg_hip.so")
 HOST_LIB = os.path.join(CSRC, "libd4pg_host.so")

@@ -10,6 +10,8 @@
 * :class:`DevicePlanar` — ``envs/planar.py`` (Hopper, Walker2d, HalfCheetah, BipedalWalker: articulated bodies
   with ground contact), one thread per environment, mass matrix and Cholesky solve in registers
   (``csrc/planar_env.hip``).
+* :class:`DeviceAnt` — ``envs/spatial.py::AntVec`` (3-D articulated body, 14 x 14 mass matrix, implicit contact;
+  ``csrc/ant_env.hip``).
 * :class:`DeviceSynthetic` — ``envs/synthetic.py::SyntheticVec`` for any observation / action shape (the same
   fixed dynamics matrices), so that the throughput configurations (Ant: 111 / 8, ...) can run their explorers
   on the GPU as well.
@@ -207,6 +209,58 @@ class DevicePlanar(_DeviceEnvBase):
         self.ep_return.zero_()
 
 
+class DeviceAnt(_DeviceEnvBase):
+    """``envs/spatial.py::AntVec`` on the device (``csrc/ant_env.hip``): the ant's topology is compiled in, every
+    number is read from the host class."""
+    STRIDE = 32
+
+    def __init__(self, num_envs: int, device="cuda", seed: int = 0, time_limit: int = 1000, limit_terminal: bool = True):
+        from .spatial import AntVec
+        host = AntVec(1)
+        super().__init__(num_envs, 111, 8, device, seed, time_limit)
+        self.state = torch.zeros(self.E, self.STRIDE, dtype=torch.float32, device=self.device)
+        self.limit_terminal = bool(limit_terminal)
+        self.params = self._params(host)
+        self._params_dev = torch.frombuffer(bytearray(bytes(self.params)), dtype=torch.uint8).to(self.device)
+
+    @staticmethod
+    def _params(host) -> H.AntParams:
+        m, p = host.model, H.AntParams()
+        if len(m.links) != 9 or len(m.contacts) != 13:
+            raise ValueError("the ant kernel is compiled for 9 links and 13 contact spheres")
+        for i, l in enumerate(m.links):
+            for k in range(3):
+                p.anchor[i][k], p.axis[i][k], p.com[i][k] = l.anchor[k], l.axis[k], l.com[k]
+            inertia = np.asarray(l.inertia, float).reshape(9)
+            for k in range(9):
+                p.inertia[i][k] = inertia[k]
+            p.mass[i], p.damping[i], p.armature[i] = l.mass, l.damping, l.armature
+            p.lo[i], p.hi[i] = max(l.limits[0], -1e30), min(l.limits[1], 1e30)
+            p.parent[i] = l.parent
+        for c, (link, local, rad) in enumerate(m.contacts):
+            for k in range(3):
+                p.c_local[c][k] = local[k]
+            p.c_rad[c], p.c_link[c] = rad, link
+        p.gravity, p.k_contact, p.c_contact, p.c_friction, p.mu = m.gravity, m.k_contact, m.c_contact, m.c_friction, m.mu
+        p.k_limit, p.c_limit = m.k_limit, m.c_limit
+        p.dt, p.substeps, p.gear, p.z_init, p.reset_noise = host.DT, host.SUBSTEPS, host.GEAR, host.Z_INIT, host.RESET_NOISE
+        p.ctrl_cost, p.contact_cost, p.alive = host.CTRL_COST, host.CONTACT_COST, host.ALIVE
+        p.z_min, p.z_max = host.HEALTHY_Z
+        for k in range(4):
+            p.ankle0[k] = host._ankle0[k]
+        p.n_links, p.n_contacts = 9, 13
+        return p
+
+    def _args(self, init: int) -> H.AntEnvArgs:
+        a = H.AntEnvArgs()
+        self._fill(a, init)
+        a.P, a.limit_terminal, a.reward_scale = self._params_dev.data_ptr(), int(self.limit_terminal), self.reward_scale
+        return a
+
+    def _launch(self, a) -> None:
+        H._check(H.lib().d4pg_ant_env_step(H.C.byref(a), H.C.byref(self.params), H.stream_ptr(None)), "d4pg_ant_env_step")
+
+
 class DeviceSynthetic(_DeviceEnvBase):
     def __init__(self, env_name: str, num_envs: int, state_dim: int, action_dim: int, device="cuda", seed: int = 0,
                  time_limit: int = 1000, terminal_prob: float = 0.001, noise_std: float = 0.05):
@@ -254,5 +308,5 @@ def make_device_env(cfg, num_envs: int, device, seed: int = 0):
     if name.startswith("InvertedDoublePendulum-"):
         return DeviceAnalytic(1, num_envs, device, seed, time_limit=limit)
     if name.startswith("Ant-"):
-        return None              # dynamics that exist on the host only (envs/spatial.py)
+        return DeviceAnt(num_envs, device, seed, time_limit=limit)
     return DeviceSynthetic(name, num_envs, cfg["state_dim"], cfg["action_dim"], device, seed, time_limit=limit)

@@ -319,6 +319,27 @@ class PlanarEnvArgs(C.Structure):
                 ("limit_terminal", C.c_int), ("kind", C.c_int), ("reward_scale", C.c_float)]
 
 
+class AntParams(C.Structure):
+    """Numbers of the ant and its task (csrc/ant_env.hip); filled from ``envs/spatial.py::AntVec``."""
+    _f9, _f93, _f99, _f13, _f133 = C.c_float * 9, (C.c_float * 3) * 9, (C.c_float * 9) * 9, C.c_float * 13, (C.c_float * 3) * 13
+    _fields_ = [("anchor", _f93), ("axis", _f93), ("com", _f93), ("mass", _f9), ("inertia", _f99), ("lo", _f9), ("hi", _f9),
+                ("damping", _f9), ("armature", _f9), ("c_local", _f133), ("c_rad", _f13),
+                ("gravity", C.c_float), ("k_contact", C.c_float), ("c_contact", C.c_float), ("c_friction", C.c_float),
+                ("mu", C.c_float), ("k_limit", C.c_float), ("c_limit", C.c_float),
+                ("dt", C.c_float), ("gear", C.c_float), ("z_init", C.c_float), ("reset_noise", C.c_float),
+                ("ctrl_cost", C.c_float), ("contact_cost", C.c_float), ("alive", C.c_float), ("z_min", C.c_float),
+                ("z_max", C.c_float), ("ankle0", C.c_float * 4),
+                ("substeps", C.c_int), ("n_links", C.c_int), ("n_contacts", C.c_int), ("pad_", C.c_int),
+                ("parent", C.c_int * 9), ("c_link", C.c_int * 13)]
+
+
+class AntEnvArgs(C.Structure):
+    _fields_ = [("P", vp), ("state", vp), ("t", vp), ("ep_return", vp), ("action", vp), ("obs", vp), ("next_obs", vp),
+                ("reward", vp), ("done", vp), ("trunc", vp), ("noise", vp), ("stats", vp), ("counter", vp),
+                ("seed", C.c_ulonglong), ("E", C.c_int), ("ld_act", C.c_int), ("time_limit", C.c_int), ("init", C.c_int),
+                ("limit_terminal", C.c_int), ("reward_scale", C.c_float)]
+
+
 class AnalyticEnvArgs(C.Structure):
     _fields_ = [("state", vp), ("t", vp), ("ep_return", vp), ("action", vp), ("obs", vp), ("next_obs", vp),
                 ("reward", vp), ("done", vp), ("trunc", vp), ("noise", vp), ("stats", vp), ("counter", vp),
@@ -430,6 +451,7 @@ def lib() -> C.CDLL:
             ("d4pg_lander_step", [C.POINTER(LanderArgs), vp]),
             ("d4pg_planar_env_step", [C.POINTER(PlanarEnvArgs), C.POINTER(PlanarParams), vp]),
             ("d4pg_analytic_env_step", [C.POINTER(AnalyticEnvArgs), vp]),
+            ("d4pg_ant_env_step", [C.POINTER(AntEnvArgs), C.POINTER(AntParams), vp]),
             ("d4pg_rollout_rows", [C.POINTER(RolloutRowsArgs), vp]),
             ("d4pg_ipc_alloc", [C.c_size_t, C.POINTER(vp), C.c_char_p]),
             ("d4pg_ipc_open", [C.c_char_p, C.POINTER(vp)]),

@@ -137,3 +137,67 @@ def test_ant_is_deterministic_and_survives_random_torques():
         outs.append(tr)
     for (o1, r1, d1), (o2, r2, d2) in zip(*outs):
         assert np.array_equal(o1, o2) and np.array_equal(r1, r2) and np.array_equal(d1, d2)
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_device_ant_follows_the_host_simulator():
+    """csrc/ant_env.hip (fp32) against envs/spatial.py (fp64): ONE step from identical states with identical
+    actions, then the host follows the device.  Touch-down is a threshold and the friction cone a switch, so a few
+    environments per step may disagree within rounding."""
+    import torch
+    from d4pg_pytorch_amd.envs.device_envs import DeviceAnt, make_device_env
+    E, limit = 256, 150
+    cfg = default_config(env="Ant-v2", model="d4pg", device="cuda", max_ep_length=limit)
+    dev = make_device_env(cfg, E, "cuda", seed=5)
+    assert isinstance(dev, DeviceAnt)
+    obs = torch.zeros(E, 111, device="cuda")
+    dev.reset(obs)
+    torch.cuda.synchronize()
+    st = dev.state.cpu().double().numpy()
+    assert np.abs(st[:, :2]).max() <= 0.1 and np.abs(st[:, 2] - 0.75).max() <= 0.1 + 1e-6
+    np.testing.assert_allclose(np.linalg.norm(st[:, 3:7], axis=1), 1.0, atol=1e-6)
+    assert 0.07 < st[:, 15:29].std() < 0.13                                       # normal deviates x 0.1
+    host = AntVec(E, seed=0, time_limit=limit)
+    host.reset()
+
+    def follow():
+        st = dev.state.cpu().double().numpy()
+        s = host.sim
+        s.pos[:], s.quat[:], s.qj[:], s.u[:] = st[:, 0:3], st[:, 3:7], st[:, 7:15], st[:, 15:29]
+        host.t[:] = dev.t.cpu().numpy()
+    follow()
+    np.testing.assert_allclose(obs.cpu().numpy()[:, :27], host._obs()[:, :27], rtol=1e-5, atol=1e-6)
+    assert not obs[:, 27:].any()
+    nobs, rew, done, trunc = (torch.zeros(E, 111, device="cuda"), torch.zeros(E, device="cuda"),
+                              torch.zeros(E, device="cuda"), torch.zeros(E, device="cuda"))
+    g = torch.Generator().manual_seed(2)
+    ended_total, touched = 0, 0
+    for t in range(200):
+        act = (torch.rand(E, 8, generator=g) * 2.6 - 1.3)
+        act[: E // 4] = 0.0
+        act[E // 4: E // 2] *= 0.3
+        act = act.cuda()
+        dev.step(act, obs, nobs, rew, done, trunc)
+        torch.cuda.synchronize()
+        o_h, r_h, d_h = host._step(act.cpu().numpy())
+        o_d = nobs.cpu().numpy()
+        # positions, angles, velocities; the clipped contact wrenches switch between -1 and 1 at a touch: compared in the mean
+        close = np.all(np.abs(o_d[:, :27] - o_h[:, :27]) <= 5e-3 + 5e-3 * np.abs(o_h[:, :27]), axis=1)
+        assert close.mean() > 0.95, (t, np.abs(o_d[:, :27] - o_h[:, :27]).max(axis=1))
+        assert np.abs(o_d[close, 27:] - o_h[close, 27:]).mean() < 0.02
+        touched += int((np.abs(o_d[:, 27:]).max(axis=1) > 0).sum())
+        d_d = done.cpu().numpy() > 0.5
+        agree = (d_d == d_h) & close
+        assert agree.mean() > 0.95
+        np.testing.assert_allclose(rew.cpu().numpy()[agree], r_h[agree], rtol=5e-3, atol=0.05)
+        assert not trunc.any()
+        ended = torch.from_numpy(d_d).cuda()
+        ended_total += int(d_d.sum())
+        assert torch.equal(obs[~ended], nobs[~ended]) and (dev.t[ended] == 0).all()
+        follow()
+    mean_ret, count = dev.episode_stats()
+    assert count == ended_total and count >= E and np.isfinite(mean_ret)
+    assert touched > 50 * E and torch.isfinite(dev.state).all()
