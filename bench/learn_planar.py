@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Learning runs on the planar articulated-body tasks with device-resident explorers (``csrc/planar_env.hip``),
+"""Learning runs on the articulated-body and closed-form tasks with device-resident explorers (``csrc/planar_env.hip``,
+``csrc/ant_env.hip``, ``csrc/analytic_env.hip``),
 the fused fp32 learner and the reference's hyper-parameters (batch 256, 400-wide nets, lr 5e-4, tau 0.001,
 gamma 0.99, 5-step returns, 51 atoms): nothing but the evaluation result leaves the GPU.
 
@@ -17,12 +18,13 @@ from d4pg_pytorch_amd.utils.learning import train_pendulum_on_device   # noqa: E
 
 #: value support = the range discounted returns can take (gamma 0.99), episode limit of the task
 TASKS = {"Hopper-v2": (0.0, 400.0, 1000), "Walker2d-v2": (0.0, 400.0, 1000), "HalfCheetah-v2": (-50.0, 600.0, 1000),
-         "BipedalWalker-v2": (-100.0, 300.0, 1600)}
+         "BipedalWalker-v2": (-100.0, 300.0, 1600), "Ant-v2": (0.0, 300.0, 1000), "Reacher-v2": (-40.0, 0.0, 50),
+         "InvertedDoublePendulum-v2": (0.0, 1000.0, 1000)}
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--env", nargs="*", default=list(TASKS))
+    ap.add_argument("--env", nargs="*", default=["Hopper-v2", "Walker2d-v2", "HalfCheetah-v2", "BipedalWalker-v2"])
     ap.add_argument("--seeds", type=int, default=1)
     ap.add_argument("--updates", type=int, default=200000)
     ap.add_argument("--model", default="d4pg")
