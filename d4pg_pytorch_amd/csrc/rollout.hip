@@ -247,7 +247,7 @@ constexpr float MASS = 4.96f, INERTIA = 0.864f, GRAVITY = -10.f;
 constexpr float MAIN_ACC = 13.f * (4.f / 30.f) / MASS * FPS, SIDE_ACC = 0.6f * (12.f / 30.f) / MASS * FPS;
 constexpr float SIDE_ANG_ACC = 0.6f * (12.f / 30.f) * (14.f / 30.f) / INERTIA * FPS;
 constexpr int SUBSTEPS = 4, REST_STEPS = 20;
-constexpr float K_SPRING = 4000.f, C_DAMP = 120.f, C_FRICTION = 60.f, INIT_SPEED = 4.f;
+constexpr float K_SPRING = 4000.f, C_DAMP = 120.f, C_FRICTION = 60.f, INIT_SPEED = 4.f, LEG_TRAVEL = 0.04f;
 __device__ __forceinline__ void observe(const float* q, float c0, float c1, float* o) {
     o[0] = (q[0] - W / 2.f) / (W / 2.f);
     o[1] = (q[1] - (PAD_Y + LEG_DOWN)) / (H / 2.f);
@@ -282,6 +282,7 @@ __global__ __launch_bounds__(256) void lander_step_kernel(const LanderArgs a) {
         const float side = fabsf(a1) > 0.5f ? a1 : 0.f;
         const float h = 1.f / (FPS * SUBSTEPS);
         c0 = c1 = 0.f;
+        bool broke = false;          // a foot pushed in beyond the leg's travel: the leg gives way
         for (int sub = 0; sub < SUBSTEPS; ++sub) {
             const float s = sinf(q[4]), c = cosf(q[4]);
             float ax = -s * MAIN_ACC * main_p + c * SIDE_ACC * side;
@@ -292,6 +293,7 @@ __global__ __launch_bounds__(256) void lander_step_kernel(const LanderArgs a) {
                 const float fxb = k == 0 ? -FOOT_X : FOOT_X;
                 const float rx = c * fxb + s * LEG_DOWN, ry = s * fxb - c * LEG_DOWN;
                 const float pen = PAD_Y - (q[1] + ry);
+                broke = broke || pen > LEG_TRAVEL;
                 if (pen > 0.f) {
                     const float fvx = q[2] - q[5] * ry, fvy = q[3] + q[5] * rx;
                     const float fn = fmaxf(0.f, K_SPRING * pen - C_DAMP * fvy), ft = -C_FRICTION * fvx;
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(256) void lander_step_kernel(const LanderArgs a) {
         const bool still = c0 > 0.f && c1 > 0.f && sqrtf(q[2] * q[2] + q[3] * q[3]) < 0.05f && fabsf(q[5]) < 0.05f;
         rest = still ? rest + 1.f : 0.f;
         const bool landed = rest >= (float)REST_STEPS;
-        const bool failed = lowest < PAD_Y || fabsf(o[0]) >= 1.f;
+        const bool failed = lowest < PAD_Y || broke || fabsf(o[0]) >= 1.f;
         rew = failed ? -100.f : (landed ? 100.f : rew);
         const bool limit = a.time_limit > 0 && t >= a.time_limit;
         const bool term = failed || landed;

@@ -18,7 +18,8 @@ Units and constants (world units = gym's pixels / 30; 50 simulation steps per se
 * ``|a[1]| > 0.5`` fires a side engine at ``|a[1]|`` power: lateral acceleration ``2.42 · power`` along
   ``sign(a[1]) · (cos θ, sin θ)`` and angular acceleration ``−sign(a[1]) · 6.48 · power``
 * two feet at body coordinates ``(±0.667, −0.6)``: spring-damper normal force, viscous friction; the hull's
-  own corners touching the ground is a crash
+  own corners touching the ground is a crash, and so is a foot pushed in by more than 0.04 (the leg gives way:
+  touching down faster than about 3 units/s; free fall arrives at 13.7, half throttle at about 5)
 * observation ``[(x−10)/10, (y−3.93)/6.67, vx·10/50, vy·6.67/50, θ, 20·ω/50, left contact, right contact]``
 * reward: change of ``−100·|pos| − 100·|vel| − 100·|θ| + 10·contacts`` minus ``0.30·main power`` and
   ``0.03·side power`` per step; −100 and done on a crash or when ``|obs[0]| ≥ 1``; +100 and done once the
@@ -47,6 +48,7 @@ SIDE_ANG_ACC = 0.6 * (12.0 / 30.0) * (14.0 / 30.0) / INERTIA * FPS      # 6.48
 SUBSTEPS = 4
 K_SPRING, C_DAMP, C_FRICTION = 4000.0, 120.0, 60.0       # per foot: N / unit, N s / unit
 REST_STEPS = 20
+LEG_TRAVEL = 0.04                # a foot pushed in further than this: the leg gives way, the hull hits the ground
 INIT_SPEED = 4.0
 
 
@@ -103,6 +105,7 @@ class LunarLanderVec(VecEnv):
         h = 1.0 / (FPS * SUBSTEPS)
         c0 = np.zeros(self.num_envs)
         c1 = np.zeros(self.num_envs)
+        broke = np.zeros(self.num_envs, bool)
         for _ in range(SUBSTEPS):
             s, c = np.sin(th), np.cos(th)
             ax = -s * MAIN_ACC * main + c * SIDE_ACC * side
@@ -113,6 +116,7 @@ class LunarLanderVec(VecEnv):
                 ry = s * fx_body - c * LEG_DOWN
                 pen = PAD_Y - (y + ry)
                 on = pen > 0.0
+                broke |= pen > LEG_TRAVEL
                 fvx = vx - om * ry                              # foot velocity
                 fvy = vy + om * rx
                 fn = np.where(on, np.maximum(0.0, K_SPRING * pen - C_DAMP * fvy), 0.0)
@@ -139,7 +143,7 @@ class LunarLanderVec(VecEnv):
         lowest = np.minimum.reduce([
             y + s * (-HULL_HALF_W) + c * HULL_BOTTOM, y + s * HULL_HALF_W + c * HULL_BOTTOM,
             y + s * (-HULL_TOP_HALF_W) + c * HULL_TOP, y + s * HULL_TOP_HALF_W + c * HULL_TOP])
-        crashed = lowest < PAD_Y
+        crashed = (lowest < PAD_Y) | broke
         obs = lander_obs(x, y, vx, vy, th, om, c0, c1)
         shaping = lander_shaping(obs)
         reward = shaping - self.prev_shaping - 0.30 * main - 0.03 * np.abs(side)

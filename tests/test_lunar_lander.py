@@ -152,3 +152,19 @@ def test_device_lander_follows_the_host_lander():
     mean_ret, n = dev.episode_stats()
     assert n > E and outcomes["crash"] > 20 and outcomes["land"] > 20, (n, outcomes)
     assert -400.0 < mean_ret < 300.0
+
+
+def test_falling_or_sinking_at_half_throttle_is_a_crash():
+    """Touch-down speed matters: with the engine off (13.7 units/s at the pad) or held at its minimum power (about
+    5 units/s) the legs give way; only a controlled descent lands."""
+    for a0 in (-0.5, 0.001):
+        env = LunarLanderVec(64, seed=3, time_limit=1000)
+        env.reset()
+        total, alive = np.zeros(64), np.ones(64, bool)
+        for _ in range(1000):
+            _, r, d = env._step(np.tile([a0, 0.0], (64, 1)))
+            total += r * alive
+            alive &= ~d
+            if not alive.any():
+                break
+        assert not alive.any() and (total < 0).mean() > 0.9 and (total > 200).sum() == 0
