@@ -18,7 +18,7 @@ from d4pg_pytorch_amd.utils.learning import train_pendulum_on_device   # noqa: E
 
 #: value support = the range discounted returns can take (gamma 0.99), episode limit of the task
 TASKS = {"Hopper-v2": (0.0, 400.0, 1000), "Walker2d-v2": (0.0, 400.0, 1000), "HalfCheetah-v2": (-50.0, 600.0, 1000),
-         "BipedalWalker-v2": (-100.0, 300.0, 1600), "Ant-v2": (0.0, 300.0, 1000), "Reacher-v2": (-40.0, 0.0, 50),
+         "BipedalWalker-v2": (-100.0, 300.0, 1600), "Ant-v2": (0.0, 300.0, 1000), "Reacher-v2": (-12.0, 0.0, 50),
          "InvertedDoublePendulum-v2": (0.0, 1000.0, 1000)}
 
 
@@ -33,12 +33,16 @@ def main():
     ap.add_argument("--segment", type=int, default=32)
     ap.add_argument("--eval-every", type=int, default=10000)
     ap.add_argument("--tau", type=float, default=0.001)
+    ap.add_argument("--v-min", type=float, default=None)
+    ap.add_argument("--v-max", type=float, default=None)
     ap.add_argument("--out", default="gpurun_out/planar")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     with open(os.path.join(args.out, "runs.jsonl"), "a") as fh:
         for env in args.env:
             v_min, v_max, limit = TASKS[env]
+            v_min = args.v_min if args.v_min is not None else v_min
+            v_max = args.v_max if args.v_max is not None else v_max
             for seed in range(args.seeds):
                 r = train_pendulum_on_device(args.model, args.core, args.updates, seed=300 + seed, envs=args.envs,
                                              segment=args.segment, eval_every=args.eval_every, env=env, max_ep_length=limit,
