@@ -20,7 +20,7 @@ from typing import List
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 HIP_SOURCES = ["gemm.hip", "loss.hip", "optim.hip", "replay.hip", "nstep.hip", "fused.hip", "fused32.hip", "rollout.hip", "planar_env.hip", "analytic_env.hip", "ant_env.hip"]
-HOST_SOURCES = ["host_runtime.cpp"]
+HOST_SOURCES = ["host_runtime.cpp", "planar_host.cpp"]
 HIP_LIB = os.path.join(CSRC, "libd4pg_hip.so")
 HOST_LIB = os.path.join(CSRC, "libd4pg_host.so")
 ARCH = "gfx950"
@@ -58,7 +58,7 @@ FUSED_PARTS = {"fused.hip": (-1, 13, 4, 8, 0), "fused32.hip": (-1, 13, 4, 8)}
 
 def build_hip(force: bool = False, verbose: bool = False) -> str:
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    headers = [os.path.join(CSRC, h) for h in ("common.h", "loss_dev.h", "replay_dev.h", "phase_common.h", "mlp32_dev.h")]
+    headers = [os.path.join(CSRC, h) for h in ("common.h", "loss_dev.h", "replay_dev.h", "phase_common.h", "mlp32_dev.h", "planar_sim.h", "ant_sim.h")]
     deps = srcs + headers
     if not force and not _stale(HIP_LIB, deps):
         return HIP_LIB
@@ -99,7 +99,7 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
 
 def build_host(force: bool = False, verbose: bool = False) -> str:
     srcs = [os.path.join(CSRC, s) for s in HOST_SOURCES]
-    if not force and not _stale(HOST_LIB, srcs):
+    if not force and not _stale(HOST_LIB, srcs + [os.path.join(CSRC, "planar_sim.h"), os.path.join(CSRC, "ant_sim.h")]):
         return HOST_LIB
     tmp = HOST_LIB + ".tmp"
     cmd = ["g++", "-O3", "-march=x86-64-v3", "-fPIC", "-shared", "-std=c++17", "-pthread", "-fopenmp-simd"] + srcs + \

@@ -89,6 +89,8 @@ EXTENSION_DEFAULTS: Dict[str, Any] = {
                                      # | "auto": replicated up to a global batch of 2048 rows in fp32 (8192 in bf16), else grad_allreduce
     "exploiter_device": None,        # default: same as ``device``
     "envs_per_agent": 1,             # vectorised environments per explorer/exploiter process
+    "env_backend": "auto",           # articulated-body tasks on the host: "native" = C++ host runtime (csrc/planar_host.cpp),
+                                     # "numpy" = the fp64 simulator written out in numpy (envs/planar.py), "auto" = native if built
     "gpu_rollout_envs": 0,           # > 0: that many explorer environments stepped ON the learner's GPU (policy, noise,
                                      # dynamics, n-step rows and replay insert without a host hop; envs/device_pendulum.py)
     "gpu_rollout_segment": 32,       # environment steps per captured rollout segment

@@ -10,8 +10,8 @@ Resolution order for ``config['env']``:
 4. native implementation of the task (``LunarLanderContinuous-v2`` -> :class:`LunarLanderVec`, own planar
    rigid-body simulation; ``Reacher-v2`` -> :class:`ReacherVec` and ``InvertedDoublePendulum-v2`` ->
    :class:`InvertedDoublePendulumVec`, closed-form dynamics; ``BipedalWalker-v2``, ``Hopper-v2``, ``Walker2d-v2``,
-   ``HalfCheetah-v2`` -> the planar articulated-body engine of ``envs/planar.py``; ``Ant-v2`` -> the 3-D one of
-   ``envs/spatial.py``) or analytic stand-in of the same shape (``InvertedPendulum-v2`` -> cart-pole)
+   ``HalfCheetah-v2`` -> the planar articulated-body engine of ``envs/planar.py``, stepped by the C++ host runtime
+   where it is built (``envs/native_planar.py``, ``env_backend``); ``Ant-v2`` -> the 3-D one of ``envs/spatial.py``) or analytic stand-in of the same shape (``InvertedPendulum-v2`` -> cart-pole)
 5. shape-only synthetic environment (with a warning), so that every shipped
    id can at least run the full pipeline (every id the reference ships a configuration for resolves above).
 """
@@ -56,6 +56,14 @@ def create_env_wrapper(config, num_envs=None, seed=None) -> VecEnv:
               "HalfCheetah-": HalfCheetahVec, "Ant-": AntVec}
     for prefix, cls in planar.items():
         if name.startswith(prefix) and not name.startswith("BipedalWalkerHardcore"):
+            backend = config.get("env_backend", "auto")
+            if backend not in ("auto", "native", "numpy"):
+                raise ValueError(f"env_backend must be auto, native or numpy, got {backend!r}")
+            from . import native_planar
+            if cls in native_planar.NATIVE and (backend == "native" or (backend == "auto" and native_planar.host_step_fn())):
+                cls = native_planar.NATIVE[cls]            # the same task, stepped by the C++ host runtime
+            elif cls is AntVec and (backend == "native" or (backend == "auto" and native_planar.ant_host_step_fn())):
+                cls = native_planar.NativeAntVec
             return cls(E, seed, time_limit=config["max_ep_length"], env_name=name)
     if name == "InvertedPendulum-v2":
         return CartPoleContinuousVec(E, seed, time_limit=config["max_ep_length"], env_name=name)

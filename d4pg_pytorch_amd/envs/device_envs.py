@@ -138,54 +138,17 @@ class DevicePlanar(_DeviceEnvBase):
     """``envs/planar.py`` (Hopper, Walker2d, HalfCheetah, BipedalWalker) on the device: the mechanism's topology
     is compiled into ``csrc/planar_env.hip``; every number (masses, lengths, gains, task coefficients) is read
     from the host class, so the two cannot drift apart."""
-    KINDS = {"HopperVec": 0, "Walker2dVec": 1, "HalfCheetahVec": 2, "BipedalWalkerVec": 3}
     STRIDE = 24
 
     def __init__(self, host_cls, num_envs: int, device="cuda", seed: int = 0, time_limit: int = 1000, limit_terminal: bool = True):
         host = host_cls(1)
         super().__init__(num_envs, host.state_dim, host.action_dim, device, seed, time_limit)
-        self.kind = self.KINDS[host_cls.__name__]
+        from .native_planar import planar_params
+        self.params, self.kind = planar_params(host)
         self.state = torch.zeros(self.E, self.STRIDE, dtype=torch.float32, device=self.device)
         self.limit_terminal = bool(limit_terminal)
         self.n = host.model.n
-        self.params = self._params(host)
         self._params_dev = torch.frombuffer(bytearray(bytes(self.params)), dtype=torch.uint8).to(self.device)
-
-    @staticmethod
-    def _pack(values) -> int:
-        out = 0
-        for i, v in enumerate(values):
-            out |= (int(v) + 1) << (4 * i)
-        return out
-
-    def _params(self, host) -> H.PlanarParams:
-        m, p = host.model, H.PlanarParams()
-        if len(m.links) > 8 or len(m.contacts) > 8:
-            raise ValueError("planar device kernels hold at most 8 links and 8 contact points")
-        for i, l in enumerate(m.links):
-            p.anchor[i][0], p.anchor[i][1] = l.anchor
-            p.com[i][0], p.com[i][1] = l.com
-            p.mass[i], p.inertia[i], p.rest[i] = l.mass, l.inertia, l.rest
-            p.lo[i], p.hi[i] = max(l.limits[0], -1e30), min(l.limits[1], 1e30)
-            p.damping[i], p.armature[i], p.stiffness[i] = l.damping, l.armature, l.stiffness
-        for c, (link, local) in enumerate(m.contacts):
-            p.c_local[c][0], p.c_local[c][1] = local
-        p.gravity, p.k_contact, p.c_contact, p.c_friction, p.mu = m.gravity, m.k_contact, m.c_contact, m.c_friction, m.mu
-        p.k_limit, p.c_limit = m.k_limit, m.c_limit
-        p.n_links, p.n_contacts, p.n_act = len(m.links), len(m.contacts), host.action_dim
-        p.parents = self._pack(l.parent for l in m.links)
-        p.contact_links = self._pack(link for link, _ in m.contacts)
-        big = 1e30
-        if self.kind == 3:
-            p.dt, p.substeps = 1.0 / host.FPS, host.SUBSTEPS
-        else:
-            p.dt, p.substeps = host.DT, host.SUBSTEPS
-            for j, g in enumerate(host.gears):
-                p.gear[j] = g
-            p.alive, p.ctrl_cost, p.reset_noise, p.q0_y = host.ALIVE, host.CTRL_COST, host.RESET_NOISE, host.q0_y
-            # healthy: z_min <= q[1] + z_off <= z_max and |root angle| <= ang_max (the rules of _unhealthy() of each class)
-            p.z_off, p.z_min, p.z_max, p.ang_max = {0: (0.2, 0.7, big, 0.2), 1: (0.2, 0.8, 2.0, 1.0), 2: (0.0, -big, big, big)}[self.kind]
-        return p
 
     def _args(self, init: int) -> H.PlanarEnvArgs:
         a = H.PlanarEnvArgs()
@@ -220,36 +183,9 @@ class DeviceAnt(_DeviceEnvBase):
         super().__init__(num_envs, 111, 8, device, seed, time_limit)
         self.state = torch.zeros(self.E, self.STRIDE, dtype=torch.float32, device=self.device)
         self.limit_terminal = bool(limit_terminal)
-        self.params = self._params(host)
+        from .native_planar import ant_params
+        self.params = ant_params(host)
         self._params_dev = torch.frombuffer(bytearray(bytes(self.params)), dtype=torch.uint8).to(self.device)
-
-    @staticmethod
-    def _params(host) -> H.AntParams:
-        m, p = host.model, H.AntParams()
-        if len(m.links) != 9 or len(m.contacts) != 13:
-            raise ValueError("the ant kernel is compiled for 9 links and 13 contact spheres")
-        for i, l in enumerate(m.links):
-            for k in range(3):
-                p.anchor[i][k], p.axis[i][k], p.com[i][k] = l.anchor[k], l.axis[k], l.com[k]
-            inertia = np.asarray(l.inertia, float).reshape(9)
-            for k in range(9):
-                p.inertia[i][k] = inertia[k]
-            p.mass[i], p.damping[i], p.armature[i] = l.mass, l.damping, l.armature
-            p.lo[i], p.hi[i] = max(l.limits[0], -1e30), min(l.limits[1], 1e30)
-            p.parent[i] = l.parent
-        for c, (link, local, rad) in enumerate(m.contacts):
-            for k in range(3):
-                p.c_local[c][k] = local[k]
-            p.c_rad[c], p.c_link[c] = rad, link
-        p.gravity, p.k_contact, p.c_contact, p.c_friction, p.mu = m.gravity, m.k_contact, m.c_contact, m.c_friction, m.mu
-        p.k_limit, p.c_limit = m.k_limit, m.c_limit
-        p.dt, p.substeps, p.gear, p.z_init, p.reset_noise = host.DT, host.SUBSTEPS, host.GEAR, host.Z_INIT, host.RESET_NOISE
-        p.ctrl_cost, p.contact_cost, p.alive = host.CTRL_COST, host.CONTACT_COST, host.ALIVE
-        p.z_min, p.z_max = host.HEALTHY_Z
-        for k in range(4):
-            p.ankle0[k] = host._ankle0[k]
-        p.n_links, p.n_contacts = 9, 13
-        return p
 
     def _args(self, init: int) -> H.AntEnvArgs:
         a = H.AntEnvArgs()

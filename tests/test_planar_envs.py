@@ -224,3 +224,50 @@ def test_device_planar_follows_the_host_simulator(cls, name, S, A):
     mean_ret, count = dev.episode_stats()
     assert count == ended_total and count >= E and np.isfinite(mean_ret)
     assert torch.isfinite(dev.state).all()
+
+
+@pytest.mark.parametrize("cls,name,S,A", ALL)
+def test_host_runtime_simulator_follows_the_numpy_oracle(cls, name, S, A):
+    """csrc/planar_host.cpp (the source of the device kernels built for the CPU, fp32) against envs/planar.py
+    (fp64): one step from identical states and actions.  A touch-down within rounding of a sub-step boundary
+    changes a contact force by its damper term, so single environments may differ for a step."""
+    from d4pg_pytorch_amd.envs import native_planar
+    if native_planar.host_step_fn() is None:
+        pytest.skip("host library not built")
+    cfg = default_config(env=name, model="d4pg", device="cpu", state_dim=S, action_dim=A)
+    nat = create_env_wrapper(cfg, 32, seed=1)
+    assert type(nat) is native_planar.NATIVE[cls]
+    assert type(create_env_wrapper(dict(cfg, env_backend="numpy"), 2, seed=1)) is cls
+    ref = cls(32, seed=1)
+    np.testing.assert_array_equal(nat.reset(), ref.reset())          # the same reset logic and random stream
+    rng = np.random.default_rng(0)
+    rows, close_rows, ended = 0, 0, 0
+    for t in range(250):
+        act = rng.uniform(-1.3, 1.3, (32, A))
+        act[:8] = 0.0
+        nat.sim.q[:], nat.sim.qd[:], nat.t[:] = ref.sim.q, ref.sim.qd, ref.t
+        nat.sim.contact_on[:] = ref.sim.contact_on
+        if cls is BipedalWalkerVec:
+            nat.prev_shaping[:] = ref.prev_shaping
+        o_r, r_r, d_r = ref._step(act)
+        o_n, r_n, d_n = nat._step(act)
+        close = np.all(np.abs(o_n - o_r) <= 2e-3 + 2e-3 * np.abs(o_r), axis=1)
+        rows, close_rows = rows + 32, close_rows + int(close.sum())
+        ok = close & (d_r == d_n)
+        np.testing.assert_allclose(r_n[ok], r_r[ok], rtol=2e-3, atol=0.02)
+        assert (d_r == d_n)[close].all()
+        for e in np.nonzero(d_r)[0]:
+            ref.reset_env(e)
+            ended += 1
+    assert close_rows >= 0.99 * rows and (ended > 5 or cls is HalfCheetahVec)          # the cheetah has no terminal state
+    # through the public step(): resets included, finite, and the time limit ends episodes
+    env = create_env_wrapper(dict(cfg, max_ep_length=40), 4, seed=2)
+    env.reset()
+    dones = 0
+    for t in range(100):
+        o, r, d = env.step(np.zeros((4, A)))
+        assert np.isfinite(o).all() and np.isfinite(r).all()
+        for e in np.nonzero(d)[0]:
+            env.reset_env(e)
+            dones += 1
+    assert dones >= 8

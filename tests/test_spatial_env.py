@@ -88,7 +88,7 @@ def test_ant_settles_on_four_feet_and_carries_its_weight():
 
 
 def test_ant_observation_reward_and_termination():
-    cfg = default_config(env="Ant-v2", model="d4pg", device="cpu")
+    cfg = default_config(env="Ant-v2", model="d4pg", device="cpu", env_backend="numpy")
     env = create_env_wrapper(cfg, 2, seed=3)
     assert isinstance(env, AntVec) and env.state_dim == 111 and env.action_dim == 8
     obs = env.reset()
@@ -201,3 +201,47 @@ def test_device_ant_follows_the_host_simulator():
     mean_ret, count = dev.episode_stats()
     assert count == ended_total and count >= E and np.isfinite(mean_ret)
     assert touched > 50 * E and torch.isfinite(dev.state).all()
+
+
+def test_host_runtime_ant_follows_the_numpy_oracle():
+    """csrc/planar_host.cpp + csrc/ant_sim.h (the source of the device kernel built for the CPU, fp32) against
+    envs/spatial.py (fp64): one step from identical states and actions."""
+    from d4pg_pytorch_amd.envs import native_planar
+    if native_planar.ant_host_step_fn() is None:
+        pytest.skip("host library not built")
+    cfg = default_config(env="Ant-v2", model="d4pg", device="cpu")
+    nat = create_env_wrapper(cfg, 16, seed=1)
+    assert type(nat) is native_planar.NativeAntVec
+    assert type(create_env_wrapper(dict(cfg, env_backend="numpy"), 2, seed=1)) is AntVec
+    ref = AntVec(16, seed=1)
+    np.testing.assert_array_equal(nat.reset(), ref.reset())
+    rng = np.random.default_rng(0)
+    rows = close_rows = ended = 0
+    for t in range(200):
+        act = rng.uniform(-1.3, 1.3, (16, 8))
+        act[:4] = 0.0
+        s, b = ref.sim, nat.sim
+        b.pos[:], b.quat[:], b.qj[:], b.u[:], nat.t[:] = s.pos, s.quat, s.qj, s.u, ref.t
+        o_r, r_r, d_r = ref._step(act)
+        o_n, r_n, d_n = nat._step(act)
+        close = np.all(np.abs(o_n[:, :27] - o_r[:, :27]) <= 2e-3 + 2e-3 * np.abs(o_r[:, :27]), axis=1)
+        rows, close_rows = rows + 16, close_rows + int(close.sum())
+        ok = close & (d_r == d_n)
+        np.testing.assert_allclose(r_n[ok], r_r[ok], rtol=2e-3, atol=0.02)
+        assert np.abs(o_n[ok, 27:] - o_r[ok, 27:]).mean() < 0.01
+        for e in np.nonzero(d_r)[0]:
+            ref.reset_env(e)
+            ended += 1
+    assert close_rows >= 0.99 * rows and ended > 3
+    env = create_env_wrapper(dict(cfg, max_ep_length=30), 4, seed=2)
+    obs = env.reset()
+    assert not obs[:, 27:].any()
+    dones = 0
+    for t in range(70):
+        obs, r, d = env.step(np.zeros((4, 8)))
+        assert np.isfinite(obs).all() and np.isfinite(r).all()
+        for e in np.nonzero(d)[0]:
+            fresh = env.reset_env(e)
+            assert not fresh[27:].any() and env.t[e] == 0        # a fresh episode starts without contact wrenches
+            dones += 1
+    assert dones >= 8
