@@ -5,7 +5,7 @@
 O=gpurun_out/e2e_planar
 mkdir -p $O
 name=$1; cfg=$2; upd=$3; shift; shift; shift
-timeout -k 10 ${E2E_TIMEOUT:-900} python train.py --config $cfg --set device=cuda results_path=$O/$name num_steps_train=$upd num_agents=13 envs_per_agent=8 updates_per_env_step=0.125 num_episode_save=100000 save_reward_threshold=1000000 "$@" > $O/$name.log 2>&1
+timeout -k 10 ${E2E_TIMEOUT:-900} python train.py --config $cfg --set device=cuda results_path=$O/$name num_steps_train=$upd num_agents=13 envs_per_agent=8 updates_per_env_step=0.125 num_episode_save=100000 save_reward_threshold=1000000 max_env_steps_per_agent=1000000000 "$@" > $O/$name.log 2>&1
 python - <<PY
 import glob, json, os, sys
 sys.path.insert(0, ".")
