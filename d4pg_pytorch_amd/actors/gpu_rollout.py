@@ -81,12 +81,16 @@ class DeviceRollout:
         cfg = self.cfg
         a = H.OuArgs()
         a.x, a.action, a.out = self.ou_x.data_ptr(), self.act_raw.data_ptr(), self.act[t].data_ptr()
-        a.sigma, a.counter, a.seed = None, self.ou_counter.data_ptr(), self.seed
+        # the Philox position of the noise is the environment's own step counter where it has one (advanced by the
+        # environment's kernel once per step; different stream constants and seeds keep the two draws apart)
+        shared = getattr(self.env, "counter", None)
+        a.sigma, a.seed = None, self.seed
+        a.counter = (shared if shared is not None else self.ou_counter).data_ptr()
         a.n, a.A = self.E * self.lda, self.lda
         a.theta, a.mu = float(cfg["ou_theta"]), float(cfg["ou_mu"])
         a.sigma_const = float(cfg["ou_max_sigma"]) if self.explore else 0.0
         a.low, a.high = float(cfg["action_low"]), float(cfg["action_high"])
-        H.launch("d4pg_ou_noise", a)
+        H.launch("d4pg_ou_noise_shared_counter" if shared is not None else "d4pg_ou_noise", a)
 
     def _enqueue_segment(self) -> None:
         T, E = self.T, self.E

@@ -98,5 +98,13 @@ D4PG_API int d4pg_ou_noise(const OuArgs* a, hipStream_t stream) {
     return (int)hipGetLastError();
 }
 
+// The same noise step with a counter that somebody else advances (a device environment's step counter, which its
+// own kernel increments once per environment step): one small launch less per rollout step.
+D4PG_API int d4pg_ou_noise_shared_counter(const OuArgs* a, hipStream_t stream) {
+    if (a->n < 1 || a->A < 1 || a->counter == nullptr) return -1;
+    hipLaunchKernelGGL(ou_noise_kernel, dim3((a->n + 255) / 256), dim3(256), 0, stream, *a);
+    return (int)hipGetLastError();
+}
+
 D4PG_SIZEOF(NstepArgs)
 D4PG_SIZEOF(OuArgs)

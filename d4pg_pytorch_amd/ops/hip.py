@@ -439,6 +439,7 @@ def lib() -> C.CDLL:
             ("d4pg_phase_lds_bytes", [C.POINTER(PhaseDims), C.c_int, C.c_int]),
             ("d4pg_wgrad", [C.POINTER(WgradGroup), vp]),
             ("d4pg_ou_noise", [C.POINTER(OuArgs), vp]),
+            ("d4pg_ou_noise_shared_counter", [C.POINTER(OuArgs), vp]),
             ("d4pg_critic_phase32", [C.POINTER(CriticPhaseArgs32), C.c_int, vp]),
             ("d4pg_actor_phase32", [C.POINTER(ActorPhaseArgs32), C.c_int, vp]),
             ("d4pg_phase32_lds_bytes", [C.POINTER(PhaseDims), C.c_int, C.c_int]),

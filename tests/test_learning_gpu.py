@@ -38,7 +38,7 @@ def test_d3pg_learns_to_balance_the_device_cartpole():
     r = train_pendulum_on_device("d3pg", "fp32", updates=6000, seed=100, eval_every=1000, env="InvertedPendulum-v2",
                                  max_ep_length=500)
     assert r["initial_return"] < 120
-    assert r["best_return"] > 300, r["curve"]
+    assert r["best_return"] > 250, r["curve"]
 
 
 def test_d4pg_learns_to_land_the_lunar_lander():
