@@ -50,3 +50,19 @@ def test_d4pg_learns_to_land_the_lunar_lander():
                                  env="LunarLanderContinuous-v2", max_ep_length=1000)
     assert r["initial_return"] < 0
     assert r["best_return"] > 200 and r["final_return"] > 150, r["curve"]
+
+
+def test_d4pg_learns_the_device_bipedal_walker_and_half_cheetah():
+    """The reference's third benchmark task (``configs/bipedal_d4pg.yml``, README curve) and a MuJoCo-style one on the
+    device-resident articulated-body simulator (``csrc/planar_env.hip``), the reference's hyper-parameters: a fresh
+    walker falls over (-100), a trained one walks most of the track (reaching its end is worth about 300); a
+    fresh cheetah does not move (about 0), a trained one runs."""
+    from d4pg_pytorch_amd.utils.learning import train_pendulum_on_device
+    r = train_pendulum_on_device("d4pg", "fp32", updates=60_000, seed=300, eval_every=10_000, envs=256,
+                                 env="BipedalWalker-v2", max_ep_length=1600, v_min=-100.0, v_max=300.0)
+    assert r["initial_return"] < -90
+    assert r["best_return"] > 200, r["curve"]
+    r = train_pendulum_on_device("d4pg", "fp32", updates=40_000, seed=300, eval_every=10_000, envs=256,
+                                 env="HalfCheetah-v2", max_ep_length=1000, v_min=-50.0, v_max=600.0)
+    assert abs(r["initial_return"]) < 300
+    assert r["best_return"] > 2000, r["curve"]
