@@ -188,6 +188,42 @@ class PlanarSim:
         return e
 
 
+def draw_segments(segments, w: int = 300, h: int = 200, ground_y: Optional[int] = None) -> np.ndarray:
+    """RGB frame with ``segments`` ``[((x0, y0), (x1, y1), colour), ...]`` in pixel coordinates (y down)."""
+    img = np.zeros((h, w, 3), np.uint8)
+    if ground_y is not None and ground_y < h:
+        img[max(0, ground_y):, :] = (90, 90, 90)
+    for (x0, y0), (x1, y1), col in segments:
+        n = int(max(abs(x1 - x0), abs(y1 - y0), 1)) + 1
+        xs = np.round(np.linspace(x0, x1, n)).astype(int)
+        ys = np.round(np.linspace(y0, y1, n)).astype(int)
+        ok = (xs >= 1) & (xs < w - 1) & (ys >= 1) & (ys < h - 1)
+        for dx in (-1, 0, 1):
+            for dy in (-1, 0, 1):
+                img[ys[ok] + dy, xs[ok] + dx] = col
+    return img
+
+
+def render_planar(sim: "PlanarSim", e: int, ends, view: float = 4.0, w: int = 300, h: int = 200) -> np.ndarray:
+    """Stick figure of environment ``e``, camera on the root: every link from its hinge to ``ends[link]`` (a point in
+    the link's frame) and on to the hinges of its children."""
+    ang, org = sim.frames()
+    scale = w / view
+    cx, cy = sim.q[e, 0], max(0.35 * view * h / w, sim.q[e, 1])
+
+    def px(p):
+        return (w / 2 + (p[0] - cx) * scale, h * 0.55 - (p[1] - cy) * scale)
+    palette = ((128, 102, 230), (230, 180, 60), (90, 200, 120), (230, 110, 110))
+    segs = []
+    for i, l in enumerate(sim.m.links):
+        tip = sim._world(ang[e:e + 1, i], org[e:e + 1, i], ends[i])[0]
+        segs.append((px(org[e, i]), px(tip), palette[i % len(palette)]))
+        for j, c in enumerate(sim.m.links):
+            if c.parent == i:
+                segs.append((px(org[e, i]), px(org[e, j]), palette[i % len(palette)]))
+    return draw_segments(segs, w, h, ground_y=int(px((0.0, 0.0))[1]))
+
+
 def _capsule(length: float, radius: float, density: float = 1000.0):
     """Mass and central inertia (about the axis normal to the plane) of a capsule lying in the plane."""
     m_cyl = density * np.pi * radius ** 2 * length
@@ -255,6 +291,10 @@ class BipedalWalkerVec(VecEnv):
 
     def _shaping(self) -> np.ndarray:
         return 130.0 * self.sim.q[:, 0] / self.SCALE - 5.0 * np.abs(self.sim.q[:, 2])
+
+    def render(self, e: int = 0) -> np.ndarray:
+        ends = [(34 / 30.0, 0.0)] + [(0.0, -self.LEG_H)] * 4
+        return render_planar(self.sim, e, ends, view=8.0)
 
     def _reset_env(self, e: int) -> np.ndarray:
         s = self.sim
@@ -326,6 +366,10 @@ class _MujocoPlanarVec(VecEnv):
 
     def _unhealthy(self) -> np.ndarray:
         return np.zeros(self.num_envs, bool)
+
+    def render(self, e: int = 0) -> np.ndarray:
+        ends = [tuple(2.0 * np.asarray(l.com)) for l in self.model.links]        # centres of mass sit at mid-length
+        return render_planar(self.sim, e, ends, view=4.0)
 
     def _step(self, actions: np.ndarray):
         self._act = np.clip(actions.astype(np.float64), -1.0, 1.0)

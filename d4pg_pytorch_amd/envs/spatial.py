@@ -361,6 +361,24 @@ class AntVec(VecEnv):
                             self.contact_wrenches().reshape(self.num_envs, 84)], axis=1).astype(np.float32)
         return o[idx]
 
+    def render(self, e: int = 0) -> np.ndarray:
+        """Two views of ant ``e`` side by side: from the side (x, z) and from above (x, y)."""
+        from .planar import draw_segments
+        R, o, ax = self.sim.frames()
+        w, h, scale = 300, 200, 60.0
+        c = self.sim.pos[e]
+        side = lambda p: (w * 0.25 + (p[0] - c[0]) * scale, h * 0.7 - p[2] * scale)         # noqa: E731
+        top = lambda p: (w * 0.75 + (p[0] - c[0]) * scale, h * 0.5 - (p[1] - c[1]) * scale)  # noqa: E731
+        segs = []
+        for k, leg in enumerate(self.LEGS):
+            hip, ank = 1 + 2 * k, 2 + 2 * k
+            tip = o[e, ank] + R[e, ank] @ (2 * np.asarray(leg[1]))
+            col = ((230, 180, 60), (90, 200, 120), (230, 110, 110), (110, 160, 230))[k]
+            for view in (side, top):
+                segs += [(view(o[e, 0]), view(o[e, hip]), (128, 102, 230)), (view(o[e, hip]), view(o[e, ank]), col),
+                         (view(o[e, ank]), view(tip), col)]
+        return draw_segments(segs, w, h, ground_y=int(h * 0.7))
+
     def _reset_env(self, e: int) -> np.ndarray:
         s, n = self.sim, self.RESET_NOISE
         s.pos[e] = self.rng.uniform(-n, n, 3) + (0.0, 0.0, self.Z_INIT)

@@ -26,6 +26,8 @@ def test_factory_shapes_and_determinism(cls, name, S, A):
     rng = np.random.default_rng(0)
     acts = rng.uniform(-1, 1, (12, 3, A))
     traj = [env.step(a) for a in acts]
+    frame = env.render(1)                      # what Agent.save_replay_gif records (models/agent.py:147-163)
+    assert frame.shape == (200, 300, 3) and frame.dtype == np.uint8 and (frame.sum(2) > 0).sum() > 500
     env2 = create_env_wrapper(cfg, 3, seed=7)
     env2.reset()
     for (o, r, d), a in zip(traj, acts):

@@ -78,6 +78,8 @@ def test_ant_settles_on_four_feet_and_carries_its_weight():
         obs, r, d = env.step(np.zeros((3, 8)))
     s = env.sim
     assert not d.any() and np.abs(s.u).max() < 0.05
+    frame = env.render(0)
+    assert frame.shape == (200, 300, 3) and frame.dtype == np.uint8 and (frame.sum(2) > 0).sum() > 500
     weight = s._mass.sum() * env.model.gravity
     np.testing.assert_allclose(s.contact_force[:, :, 2].sum(1), weight, rtol=0.02)
     feet = [3, 6, 9, 12]
