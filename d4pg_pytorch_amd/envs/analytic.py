@@ -73,6 +73,18 @@ class ReacherVec(VecEnv):
         det = m11 * m22 - m12 * m12
         return np.stack([(m22 * b1 - m12 * b2) / det, (m11 * b2 - m12 * b1) / det], axis=1)
 
+    def render(self, e: int = 0) -> np.ndarray:
+        from .planar import draw_segments
+        w, h, sc = 300, 200, 380.0
+        px = lambda x, y: (w / 2 + x * sc, h / 2 - y * sc)                                    # noqa: E731
+        a1, a12 = self.q[e, 0], self.q[e, 0] + self.q[e, 1]
+        elbow = (self.L1 * np.cos(a1), self.L1 * np.sin(a1))
+        tip = (elbow[0] + self.L2 * np.cos(a12), elbow[1] + self.L2 * np.sin(a12))
+        tx, ty = self.target[e]
+        segs = [(px(0, 0), px(*elbow), (128, 102, 230)), (px(*elbow), px(*tip), (230, 180, 60)),
+                (px(tx - 0.01, ty), px(tx + 0.01, ty), (230, 60, 60)), (px(tx, ty - 0.01), px(tx, ty + 0.01), (230, 60, 60))]
+        return draw_segments(segs, w, h)
+
     def _step(self, actions: np.ndarray):
         a = np.clip(actions.astype(np.float64), -1.0, 1.0)
         before = self.tip() - self.target
@@ -118,6 +130,17 @@ class InvertedDoublePendulumVec(VecEnv):
         self.qd[e] = self.rng.standard_normal(3) * 0.1
         self.t[e] = 0
         return self._obs(e)
+
+    def render(self, e: int = 0) -> np.ndarray:
+        from .planar import draw_segments
+        w, h, sc = 300, 200, 70.0
+        px = lambda x, y: (w / 2 + x * sc, h * 0.8 - y * sc)                                  # noqa: E731
+        x, a1, a2 = self.q[e]
+        j = (x + self.L1 * np.sin(a1), self.L1 * np.cos(a1))
+        tip = (j[0] + self.L2 * np.sin(a2), j[1] + self.L2 * np.cos(a2))
+        segs = [(px(-self.X_LIMIT, 0), px(self.X_LIMIT, 0), (90, 90, 90)), (px(x - 0.1, 0), px(x + 0.1, 0), (204, 204, 0)),
+                (px(x, 0), px(*j), (128, 102, 230)), (px(*j), px(*tip), (230, 180, 60))]
+        return draw_segments(segs, w, h)
 
     def _accel(self, q, qd, u):
         d1, d2, d3, d4, d5, d6, f1, f2 = self._d

@@ -190,3 +190,11 @@ def test_device_twins_follow_the_host_dynamics(name):
         assert -120.0 < mean_ret < -20.0          # 50 steps of -|a|^2 (about 1.1 at random) - distance
     else:
         assert 20.0 < mean_ret < 200.0            # a few steps of about 9 before the tip drops below 1
+
+
+def test_render_frames_for_the_replay_gif():
+    for cls in (ReacherVec, InvertedDoublePendulumVec):
+        env = cls(2, seed=0)
+        env.reset()
+        frame = env.render(1)
+        assert frame.shape == (200, 300, 3) and frame.dtype == np.uint8 and (frame.sum(2) > 0).sum() > 200
