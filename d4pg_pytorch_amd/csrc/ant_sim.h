@@ -99,23 +99,6 @@ ASIM_FN void accelerations(const AntParams* __restrict__ P, const float (&pos)[3
         F.ax[0] = v3(0.f, 0.f, 0.f);
         F.w[0] = v3(u[3], u[4], u[5]);
     }
-#pragma unroll
-    for (int i = 1; i < L; ++i) {
-        const int p = parent_of(i);
-        const V3 a = ld3(P->axis[i]);
-        float sn, cs;
-        ASIM_SINCOS(qj[i - 1], &sn, &cs);
-        // Rodrigues: I + sin K + (1 - cos) K^2, K = skew(a), K^2 = a a' - I for a unit axis
-        const float oc = 1.f - cs;
-        M3 rot;
-        rot.m[0][0] = 1.f + oc * (a.x * a.x - 1.f), rot.m[0][1] = -sn * a.z + oc * a.x * a.y, rot.m[0][2] = sn * a.y + oc * a.x * a.z;
-        rot.m[1][0] = sn * a.z + oc * a.x * a.y, rot.m[1][1] = 1.f + oc * (a.y * a.y - 1.f), rot.m[1][2] = -sn * a.x + oc * a.y * a.z;
-        rot.m[2][0] = -sn * a.y + oc * a.x * a.z, rot.m[2][1] = sn * a.x + oc * a.y * a.z, rot.m[2][2] = 1.f + oc * (a.z * a.z - 1.f);
-        F.R[i] = mul(F.R[p], rot);
-        F.o[i] = F.o[p] + mul(F.R[p], ld3(P->anchor[i]));
-        F.ax[i] = mul(F.R[p], a);
-        F.w[i] = F.w[p] + u[6 + i - 1] * F.ax[i];
-    }
     float M[N][N], Q[N];
 #pragma unroll
     for (int a = 0; a < N; ++a) {
@@ -125,52 +108,6 @@ ASIM_FN void accelerations(const AntParams* __restrict__ P, const float (&pos)[3
     }
     V3 a_o[L], alpha[L], com[L];
     a_o[0] = alpha[0] = v3(0.f, 0.f, 0.f);
-#pragma unroll
-    for (int i = 0; i < L; ++i) {
-        const int p = parent_of(i);
-        if (i > 0) {
-            const V3 r = F.o[i] - F.o[p];
-            a_o[i] = a_o[p] + cross(alpha[p], r) + cross(F.w[p], cross(F.w[p], r));
-            alpha[i] = alpha[p] + u[6 + i - 1] * cross(F.w[p], F.ax[i]);
-        }
-        const float m = P->mass[i];
-        com[i] = F.o[i] + mul(F.R[i], ld3(P->com[i]));
-        const V3 rc = com[i] - F.o[i];
-        const V3 a_c = a_o[i] + cross(alpha[i], rc) + cross(F.w[i], cross(F.w[i], rc));
-        const V3 f_lin = m * (v3(0.f, 0.f, -P->gravity) - a_c);
-        M3 I0, Iw;
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) I0.m[r][c] = P->inertia[i][3 * r + c];
-        {
-            const M3 RI = mul(F.R[i], I0);
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) Iw.m[r][c] = RI.m[r][0] * F.R[i].m[c][0] + RI.m[r][1] * F.R[i].m[c][1] + RI.m[r][2] * F.R[i].m[c][2];
-        }
-        const V3 t_rot = -1.f * (mul(Iw, alpha[i]) + cross(F.w[i], mul(Iw, F.w[i])));
-        V3 jv[N], jw[N], ijw[N];
-#pragma unroll
-        for (int c = 3; c < N; ++c) {
-            if (!active(i, c)) continue;
-            jv[c] = column(F, i, c, com[i]);
-            jw[c] = c < 6 ? v3(c == 3 ? 1.f : 0.f, c == 4 ? 1.f : 0.f, c == 5 ? 1.f : 0.f) : F.ax[c - 6 + 1];
-            ijw[c] = c < 6 ? colv(Iw, c - 3) : mul(Iw, jw[c]);
-        }
-        M[0][0] += m, M[1][1] += m, M[2][2] += m;
-        Q[0] += f_lin.x, Q[1] += f_lin.y, Q[2] += f_lin.z;
-#pragma unroll
-        for (int c = 3; c < N; ++c) {
-            if (!active(i, c)) continue;
-            M[c][0] += m * jv[c].x, M[c][1] += m * jv[c].y, M[c][2] += m * jv[c].z;
-            Q[c] += dot(jv[c], f_lin) + dot(jw[c], t_rot);
-#pragma unroll
-            for (int d = 3; d <= c; ++d)
-                if (active(i, d)) M[c][d] += m * dot(jv[c], jv[d]) + dot(jw[c], ijw[d]);
-        }
-    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int i = j + 1;
@@ -186,49 +123,123 @@ ASIM_FN void accelerations(const AntParams* __restrict__ P, const float (&pos)[3
     for (int i = 0; i < L; ++i)
 #pragma unroll
         for (int k = 0; k < 6; ++k) wrench[i][k] = 0.f;
+    // the torso (g = 0), then one leg after the other: a leg's frames, Jacobian columns and contact points are dead
+    // before the next leg starts, which shortens the live ranges of everything but M, Q and the torso's frame.
+    // (Device builds of this order at -O2 / -O3 with hipcc 7.2 return wrong accelerations; -O1 and the host build
+    // agree with the numpy simulator: csrc/ant_env.hip is built at -O1, see build.py, and tests/test_spatial_env.py
+    // holds the device build to the host simulator step by step.)
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-        const int link = contact_link(c);
-        V3 p = F.o[link] + mul(F.R[link], ld3(P->c_local[c]));
-        p.z -= P->c_rad[c];                                     // the sphere's lowest point
-        if (p.z < 0.f) {
-            V3 col[N];
-            V3 v = v3(u[0], u[1], u[2]);
+    for (int g = 0; g < 5; ++g) {
+        const int first = g == 0 ? 0 : 2 * g - 1, last = g == 0 ? 0 : 2 * g;
+        const int c_first = g == 0 ? 0 : 3 * g - 2, c_last = g == 0 ? 0 : 3 * g;
 #pragma unroll
-            for (int k = 3; k < N; ++k) {
-                if (!active(link, k)) continue;
-                col[k] = column(F, link, k, p);
-                v = v + u[k] * col[k];
+        for (int i = first; i <= last; ++i) {
+            if (i == 0) continue;
+            const int p = parent_of(i);
+            const V3 a = ld3(P->axis[i]);
+            float sn, cs;
+            ASIM_SINCOS(qj[i - 1], &sn, &cs);
+            // Rodrigues: I + sin K + (1 - cos) K^2, K = skew(a), K^2 = a a' - I for a unit axis
+            const float oc = 1.f - cs;
+            M3 rot;
+            rot.m[0][0] = 1.f + oc * (a.x * a.x - 1.f), rot.m[0][1] = -sn * a.z + oc * a.x * a.y, rot.m[0][2] = sn * a.y + oc * a.x * a.z;
+            rot.m[1][0] = sn * a.z + oc * a.x * a.y, rot.m[1][1] = 1.f + oc * (a.y * a.y - 1.f), rot.m[1][2] = -sn * a.x + oc * a.y * a.z;
+            rot.m[2][0] = -sn * a.y + oc * a.x * a.z, rot.m[2][1] = sn * a.x + oc * a.y * a.z, rot.m[2][2] = 1.f + oc * (a.z * a.z - 1.f);
+            F.R[i] = mul(F.R[p], rot);
+            F.o[i] = F.o[p] + mul(F.R[p], ld3(P->anchor[i]));
+            F.ax[i] = mul(F.R[p], a);
+            F.w[i] = F.w[p] + u[6 + i - 1] * F.ax[i];
+        }
+#pragma unroll
+        for (int i = first; i <= last; ++i) {
+            const int p = parent_of(i);
+            if (i > 0) {
+                const V3 r = F.o[i] - F.o[p];
+                a_o[i] = a_o[p] + cross(alpha[p], r) + cross(F.w[p], cross(F.w[p], r));
+                alpha[i] = alpha[p] + u[6 + i - 1] * cross(F.w[p], F.ax[i]);
             }
-            float fn = -P->k_contact * p.z - P->c_contact * v.z;
-            const bool push = fn > 0.f;
-            fn = push ? fn : 0.f;
-            float fx = -P->c_friction * v.x, fy = -P->c_friction * v.y;
-            const float norm = sqrtf(fx * fx + fy * fy), cap = P->mu * fn;
-            const bool slide = norm > cap;
-            if (slide) {
-                const float s = cap / fmaxf(norm, 1e-12f);
-                fx *= s, fy *= s;
-            }
-            if (!push) fx = fy = 0.f;
-            const V3 f = v3(fx, fy, fn);
-            Q[0] += f.x, Q[1] += f.y, Q[2] += f.z;
-            const float gxy = (push && !slide) ? h * P->c_friction : 0.f;
-            const float gz = push ? h * P->c_contact + h * h * P->k_contact : 0.f;
-            M[0][0] += gxy, M[1][1] += gxy, M[2][2] += gz;
+            const float m = P->mass[i];
+            com[i] = F.o[i] + mul(F.R[i], ld3(P->com[i]));
+            const V3 rc = com[i] - F.o[i];
+            const V3 a_c = a_o[i] + cross(alpha[i], rc) + cross(F.w[i], cross(F.w[i], rc));
+            const V3 f_lin = m * (v3(0.f, 0.f, -P->gravity) - a_c);
+            M3 I0, Iw;
 #pragma unroll
-            for (int k = 3; k < N; ++k) {
-                if (!active(link, k)) continue;
-                Q[k] += dot(col[k], f);
-                const V3 g = v3(gxy * col[k].x, gxy * col[k].y, gz * col[k].z);
-                M[k][0] += g.x, M[k][1] += g.y, M[k][2] += g.z;
+            for (int r = 0; r < 3; ++r)
 #pragma unroll
-                for (int d = 3; d <= k; ++d)
-                    if (active(link, d)) M[k][d] += dot(g, col[d]);
+                for (int c = 0; c < 3; ++c) I0.m[r][c] = P->inertia[i][3 * r + c];
+            {
+                const M3 RI = mul(F.R[i], I0);
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) Iw.m[r][c] = RI.m[r][0] * F.R[i].m[c][0] + RI.m[r][1] * F.R[i].m[c][1] + RI.m[r][2] * F.R[i].m[c][2];
             }
-            const V3 mom = cross(p - com[link], f);
-            wrench[link][0] += mom.x, wrench[link][1] += mom.y, wrench[link][2] += mom.z;
-            wrench[link][3] += f.x, wrench[link][4] += f.y, wrench[link][5] += f.z;
+            const V3 t_rot = -1.f * (mul(Iw, alpha[i]) + cross(F.w[i], mul(Iw, F.w[i])));
+            V3 jv[N], jw[N], ijw[N];
+#pragma unroll
+            for (int c = 3; c < N; ++c) {
+                if (!active(i, c)) continue;
+                jv[c] = column(F, i, c, com[i]);
+                jw[c] = c < 6 ? v3(c == 3 ? 1.f : 0.f, c == 4 ? 1.f : 0.f, c == 5 ? 1.f : 0.f) : F.ax[c - 6 + 1];
+                ijw[c] = c < 6 ? colv(Iw, c - 3) : mul(Iw, jw[c]);
+            }
+            M[0][0] += m, M[1][1] += m, M[2][2] += m;
+            Q[0] += f_lin.x, Q[1] += f_lin.y, Q[2] += f_lin.z;
+#pragma unroll
+            for (int c = 3; c < N; ++c) {
+                if (!active(i, c)) continue;
+                M[c][0] += m * jv[c].x, M[c][1] += m * jv[c].y, M[c][2] += m * jv[c].z;
+                Q[c] += dot(jv[c], f_lin) + dot(jw[c], t_rot);
+#pragma unroll
+                for (int d = 3; d <= c; ++d)
+                    if (active(i, d)) M[c][d] += m * dot(jv[c], jv[d]) + dot(jw[c], ijw[d]);
+            }
+        }
+#pragma unroll
+        for (int c = c_first; c <= c_last; ++c) {
+            const int link = contact_link(c);
+            V3 p = F.o[link] + mul(F.R[link], ld3(P->c_local[c]));
+            p.z -= P->c_rad[c];                                     // the sphere's lowest point
+            if (p.z < 0.f) {
+                V3 col[N];
+                V3 v = v3(u[0], u[1], u[2]);
+#pragma unroll
+                for (int k = 3; k < N; ++k) {
+                    if (!active(link, k)) continue;
+                    col[k] = column(F, link, k, p);
+                    v = v + u[k] * col[k];
+                }
+                float fn = -P->k_contact * p.z - P->c_contact * v.z;
+                const bool push = fn > 0.f;
+                fn = push ? fn : 0.f;
+                float fx = -P->c_friction * v.x, fy = -P->c_friction * v.y;
+                const float norm = sqrtf(fx * fx + fy * fy), cap = P->mu * fn;
+                const bool slide = norm > cap;
+                if (slide) {
+                    const float s = cap / fmaxf(norm, 1e-12f);
+                    fx *= s, fy *= s;
+                }
+                if (!push) fx = fy = 0.f;
+                const V3 f = v3(fx, fy, fn);
+                Q[0] += f.x, Q[1] += f.y, Q[2] += f.z;
+                const float gxy = (push && !slide) ? h * P->c_friction : 0.f;
+                const float gz = push ? h * P->c_contact + h * h * P->k_contact : 0.f;
+                M[0][0] += gxy, M[1][1] += gxy, M[2][2] += gz;
+#pragma unroll
+                for (int k = 3; k < N; ++k) {
+                    if (!active(link, k)) continue;
+                    Q[k] += dot(col[k], f);
+                    const V3 g = v3(gxy * col[k].x, gxy * col[k].y, gz * col[k].z);
+                    M[k][0] += g.x, M[k][1] += g.y, M[k][2] += g.z;
+#pragma unroll
+                    for (int d = 3; d <= k; ++d)
+                        if (active(link, d)) M[k][d] += dot(g, col[d]);
+                }
+                const V3 mom = cross(p - com[link], f);
+                wrench[link][0] += mom.x, wrench[link][1] += mom.y, wrench[link][2] += mom.z;
+                wrench[link][3] += f.x, wrench[link][4] += f.y, wrench[link][5] += f.z;
+            }
         }
     }
     // Cholesky M = G G' in the lower triangle, then two triangular solves
