@@ -14,7 +14,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from d4pg_pytorch_amd.utils.learning import train_pendulum_on_device   # noqa: E402
+from d4pg_pytorch_amd.utils.learning import train_on_device   # noqa: E402
 
 #: value support = the range discounted returns can take (gamma 0.99), episode limit of the task
 TASKS = {"Hopper-v2": (0.0, 400.0, 1000), "Walker2d-v2": (0.0, 400.0, 1000), "HalfCheetah-v2": (-50.0, 600.0, 1000),
@@ -44,7 +44,7 @@ def main():
             v_min = args.v_min if args.v_min is not None else v_min
             v_max = args.v_max if args.v_max is not None else v_max
             for seed in range(args.seeds):
-                r = train_pendulum_on_device(args.model, args.core, args.updates, seed=300 + seed, envs=args.envs,
+                r = train_on_device(args.model, args.core, args.updates, seed=300 + seed, envs=args.envs,
                                              segment=args.segment, eval_every=args.eval_every, env=env, max_ep_length=limit,
                                              tau=args.tau, v_min=v_min, v_max=v_max)
                 r["envs"], r["env_steps_per_update"] = args.envs, args.envs * args.segment / 32

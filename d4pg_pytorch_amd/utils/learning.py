@@ -89,11 +89,11 @@ class GreedyEvaluator:
         return float(self.first.mean().item())
 
 
-def train_pendulum_on_device(model: str = "d4pg", core: str = "fp32", updates: int = 20_000, seed: int = 0,
+def train_on_device(model: str = "d4pg", core: str = "fp32", updates: int = 20_000, seed: int = 0,
                              eval_every: int = 1000, envs: int = 8, segment: int = 32, eval_envs: int = 64,
                              warmup_segments: int = 8, device="cuda", env: str = "Pendulum-v0", **overrides) -> Dict:
-    """Train on a device-resident environment (the pendulum by default; ``env="InvertedPendulum-v2"`` is the
-    cart-pole stand-in); returns the evaluation curve and summary numbers.
+    """Train on a device-resident environment (the pendulum by default; any id ``envs/device_envs.py::make_device_env``
+    knows: the lunar lander, the articulated-body tasks, ...); returns the evaluation curve and summary numbers.
 
     ``core``: ``"torch"`` (eager PyTorch fp32, the oracle), ``"fp32"`` (fused HIP, default compute path) or
     ``"bf16"`` (fused HIP, bf16 MFMA operands).  ``envs * segment`` environment steps are collected per 32
@@ -150,3 +150,7 @@ def train_pendulum_on_device(model: str = "d4pg", core: str = "fp32", updates: i
             "initial_return": round(rets[0], 1), "final_return": round(rets[-1], 1),
             "last5_mean_return": round(sum(rets[-5:]) / len(rets[-5:]), 1), "best_return": round(max(rets), 1),
             "first_eval_step_above_-300": first, "value_loss": m.get("value_loss"), "policy_loss": m.get("policy_loss")}
+
+
+#: the name this function had while the pendulum was the only device environment
+train_pendulum_on_device = train_on_device
