@@ -19,10 +19,13 @@ struct PlanarEnvArgs {
     float* noise;            // [E][ld_act] exploration-noise state, zeroed where an episode ends; or null
     double* stats;           // [2] sum of finished episode returns, number of finished episodes
     unsigned long long* counter;
+    float* terrain;          // [200][E] ground heights of the walker (sample-major: a wavefront's 64 environments read and
+                             // write one sample as one 256-byte access), redrawn at every reset; null: flat ground
     unsigned long long seed;
     int E, ld_act, time_limit, init;
     int limit_terminal, kind;        // kind: 0 Hopper, 1 Walker2d, 2 HalfCheetah, 3 BipedalWalker
     float reward_scale;
+    int hilly;               // walker: 1 = the gym task's grass (random walk of the slope), 0 = all heights zero
 };
 
 namespace planar {
@@ -42,14 +45,15 @@ __global__ __launch_bounds__(64) void planar_step_kernel(const PlanarEnvArgs a) 
     float c0 = st[FLAG0], c1 = st[FLAG0 + 1], prev = st[PREV];
     int t = a.t[e];
     bool reset = a.init != 0;
+    float* ter = (T::TASK == 1 && a.terrain != nullptr) ? a.terrain + e : nullptr;       // sample j at ter[j * E]
     if (!a.init) {
         float rew;
         bool term;
-        advance<T>(P, q, qd, a.action + (size_t)e * a.ld_act, c0, c1, prev, rew, term);
+        advance<T>(P, q, qd, a.action + (size_t)e * a.ld_act, c0, c1, prev, rew, term, ter, a.E);
         t += 1;
         const bool limit = a.time_limit > 0 && t >= a.time_limit;
         float o[T::S];
-        observe<T>(q, qd, c0, c1, o);
+        observe<T>(q, qd, c0, c1, o, ter, a.E);
 #pragma unroll
         for (int i = 0; i < T::S; ++i) a.next_obs[(size_t)e * T::S + i] = o[i];
         a.reward[e] = rew / a.reward_scale;
@@ -90,6 +94,17 @@ __global__ __launch_bounds__(64) void planar_step_kernel(const PlanarEnvArgs a) 
             q[3] = 0.05f, q[5] = -0.05f, q[4] = -0.1f, q[6] = -0.1f;
             qd[0] = (2.f * unit(r[0]) - 1.f) * 5.f / HULL_MASS / FPS * 10.f;
             prev = 130.f * q[0] / SCALE;
+            if (ter != nullptr) {        // fresh ground: a flat start pad, then a damped random walk of the slope
+                uint32_t x = r[1] | 1u;      // xorshift32 seeded by the reset's Philox draw: 200 cheap uniforms
+                float y = 0.f, velocity = 0.f;
+                for (int i = 0; i < TERRAIN_LENGTH; ++i) {
+                    x ^= x << 13, x ^= x >> 17, x ^= x << 5;
+                    velocity = 0.8f * velocity + 0.01f * (y < 0.f ? 1.f : (y > 0.f ? -1.f : 0.f));
+                    if (i > TERRAIN_STARTPAD && a.hilly) velocity += (2.f * unit(x) - 1.f) / SCALE;
+                    y += velocity;
+                    ter[(size_t)i * a.E] = y;
+                }
+            }
         }
         c0 = c1 = 0.f;
         t = 0;
@@ -101,8 +116,13 @@ __global__ __launch_bounds__(64) void planar_step_kernel(const PlanarEnvArgs a) 
     for (int i = 0; i < n; ++i) st[i] = q[i], st[QD0 + i] = qd[i];
     st[FLAG0] = c0, st[FLAG0 + 1] = c1, st[PREV] = prev;
     a.t[e] = t;
+    if (!reset) {                    // nothing changed since next_obs was written: the policy sees the same thing
+#pragma unroll
+        for (int i = 0; i < T::S; ++i) a.obs[(size_t)e * T::S + i] = a.next_obs[(size_t)e * T::S + i];
+        return;
+    }
     float o[T::S];
-    observe<T>(q, qd, c0, c1, o);
+    observe<T>(q, qd, c0, c1, o, ter, a.E);
 #pragma unroll
     for (int i = 0; i < T::S; ++i) a.obs[(size_t)e * T::S + i] = o[i];
 }

@@ -10,7 +10,7 @@
 namespace {
 template <class T>
 int step_all(const PlanarParams* P, int E, float* state, const float* action, int ld_act, float* next_obs, float* reward,
-             uint8_t* term_out) {
+             uint8_t* term_out, const float* terrain) {
     using namespace planar;
     constexpr int n = T::L + 2;
     if (P->n_links != T::L || P->n_contacts != T::C || P->n_act != T::A || P->parents != T::PAR || P->contact_links != T::CL)
@@ -21,10 +21,11 @@ int step_all(const PlanarParams* P, int E, float* state, const float* action, in
         for (int i = 0; i < n; ++i) q[i] = st[i], qd[i] = st[QD0 + i];
         float c0 = st[FLAG0], c1 = st[FLAG0 + 1], prev = st[PREV], rew;
         bool term;
-        advance<T>(P, q, qd, action + (size_t)e * ld_act, c0, c1, prev, rew, term);
+        const float* ter = (T::TASK == 1 && terrain != nullptr) ? terrain + (size_t)e * biped::TERRAIN_LENGTH : nullptr;
+        advance<T>(P, q, qd, action + (size_t)e * ld_act, c0, c1, prev, rew, term, ter, 1);
         for (int i = 0; i < n; ++i) st[i] = q[i], st[QD0 + i] = qd[i];
         st[FLAG0] = c0, st[FLAG0 + 1] = c1, st[PREV] = prev;
-        observe<T>(q, qd, c0, c1, next_obs + (size_t)e * T::S);
+        observe<T>(q, qd, c0, c1, next_obs + (size_t)e * T::S, ter, 1);
         reward[e] = rew;
         term_out[e] = term ? 1 : 0;
     }
@@ -34,18 +35,18 @@ int step_all(const PlanarParams* P, int E, float* state, const float* action, in
 
 // kind: 0 Hopper, 1 Walker2d, 2 HalfCheetah, 3 BipedalWalker.  state [E][24] (q at 0, q' at 9, leg-contact flags at
 // 18 / 19, previous shaping at 20), action [E][ld_act], next_obs [E][S], reward [E], term [E] (terminal state of the
-// task, time limits excluded).
+// task, time limits excluded), terrain [E][200] ground heights of the walker (null: flat).
 extern "C" __attribute__((visibility("default"))) int d4pg_planar_host_step(const PlanarParams* P, int kind, int E, float* state,
                                                                             const float* action, int ld_act, float* next_obs,
-                                                                            float* reward, uint8_t* term) {
+                                                                            float* reward, uint8_t* term, const float* terrain) {
     if (P == nullptr || E < 1 || state == nullptr || action == nullptr || next_obs == nullptr || reward == nullptr || term == nullptr)
         return -1;
     if (P->substeps < 1 || P->substeps > 64 || !(P->dt > 0.f)) return -4;
     switch (kind) {
-        case 0: return ld_act < 3 ? -2 : step_all<planar::HopperT>(P, E, state, action, ld_act, next_obs, reward, term);
-        case 1: return ld_act < 6 ? -2 : step_all<planar::WalkerT>(P, E, state, action, ld_act, next_obs, reward, term);
-        case 2: return ld_act < 6 ? -2 : step_all<planar::CheetahT>(P, E, state, action, ld_act, next_obs, reward, term);
-        case 3: return ld_act < 4 ? -2 : step_all<planar::BipedT>(P, E, state, action, ld_act, next_obs, reward, term);
+        case 0: return ld_act < 3 ? -2 : step_all<planar::HopperT>(P, E, state, action, ld_act, next_obs, reward, term, terrain);
+        case 1: return ld_act < 6 ? -2 : step_all<planar::WalkerT>(P, E, state, action, ld_act, next_obs, reward, term, terrain);
+        case 2: return ld_act < 6 ? -2 : step_all<planar::CheetahT>(P, E, state, action, ld_act, next_obs, reward, term, terrain);
+        case 3: return ld_act < 4 ? -2 : step_all<planar::BipedT>(P, E, state, action, ld_act, next_obs, reward, term, terrain);
         default: return -5;
     }
 }

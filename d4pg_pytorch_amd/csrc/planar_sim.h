@@ -15,10 +15,14 @@
 #pragma once
 #include <math.h>
 #if defined(__HIPCC__)
+#define PSIM_RCP(x) __frcp_rn(x)
+#define PSIM_RSQRT(x) __frsqrt_rn(x)
 #define PSIM_FN __device__ __forceinline__
 #define PSIM_SINCOS(x, s, c) __sincosf((x), (s), (c))
 #define PSIM_FINITE(x) isfinite(x)
 #else
+#define PSIM_RCP(x) (1.f / (x))
+#define PSIM_RSQRT(x) (1.f / sqrtf(x))
 #define PSIM_FN static inline
 #define PSIM_SINCOS(x, s, c) sincosf((x), (s), (c))
 #define PSIM_FINITE(x) std::isfinite(x)
@@ -64,6 +68,45 @@ namespace biped {
 constexpr float FPS = 50.f, SCALE = 30.f, LEG_H = 34.f / 30.f, LEG_DOWN = -8.f / 30.f;
 constexpr float MOTORS_TORQUE = 80.f, SPEED_HIP = 4.f, SPEED_KNEE = 6.f, LIDAR_RANGE = 160.f / 30.f;
 constexpr float TRACK_END = (200 - 10) * 14.f / 30.f, START_X = 14.f / 30.f * 20.f / 2.f, SERVO_GAIN = 6.f, HULL_MASS = 5.42f;
+constexpr float TERRAIN_STEP = 14.f / 30.f, INV_STEP = 30.f / 14.f;
+// sine and cosine of the lidar angles 0, 0.15, ... 1.35 rad
+#define LIDAR_SIN_TABLE {0.f, 0.14943813f, 0.29552021f, 0.43496553f, 0.56464247f, 0.68163876f, 0.78332691f, 0.86742323f, 0.93203909f, 0.97572336f}
+#define LIDAR_COS_TABLE {1.f, 0.98877108f, 0.95533649f, 0.90044710f, 0.82533561f, 0.73168887f, 0.62160997f, 0.49757105f, 0.36235775f, 0.21900669f}
+constexpr int TERRAIN_LENGTH = 200, TERRAIN_STARTPAD = 20, LIDAR_SEGMENTS = 13;
+// height and slope of the ground under x: piecewise linear between the samples terrain[j] at x = j * TERRAIN_STEP
+PSIM_FN void ground(const float* __restrict__ terrain, int ts, float x, float& g, float& slope) {
+    int j = (int)floorf(x / TERRAIN_STEP);
+    j = j < 0 ? 0 : (j > TERRAIN_LENGTH - 2 ? TERRAIN_LENGTH - 2 : j);
+    const float h0 = terrain[(size_t)j * ts], h1 = terrain[(size_t)(j + 1) * ts];
+    slope = (h1 - h0) / TERRAIN_STEP;
+    g = h0 + slope * (x - (float)j * TERRAIN_STEP);
+}
+// The stretch of ground the walker can touch during one step (feet and hull corners stay within 2.5 of the hull's
+// centre), read ONCE per step: inside the sub-steps a lookup is a chain of selects on registers instead of two
+// dependent memory loads on the critical path of a latency-bound thread.
+constexpr int WINDOW = 12;
+struct TerrainWindow {
+    float h[WINDOW];
+    int j0;
+    bool on;
+};
+PSIM_FN void load_window(const float* __restrict__ terrain, int ts, float x, TerrainWindow& w) {
+    w.on = terrain != nullptr;
+    int j0 = (int)floorf((x - 2.5f) * INV_STEP);
+    w.j0 = j0 < 0 ? 0 : (j0 > TERRAIN_LENGTH - WINDOW ? TERRAIN_LENGTH - WINDOW : j0);
+#pragma unroll
+    for (int k = 0; k < WINDOW; ++k) w.h[k] = w.on ? terrain[(size_t)(w.j0 + k) * ts] : 0.f;       // ts: stride between samples
+}
+PSIM_FN void ground(const TerrainWindow& w, float x, float& g, float& slope) {
+    int j = (int)floorf(x * INV_STEP) - w.j0;
+    j = j < 0 ? 0 : (j > WINDOW - 2 ? WINDOW - 2 : j);          // beyond the window: its edge segment, extended
+    float h0 = w.h[0], h1 = w.h[1];
+#pragma unroll
+    for (int k = 1; k < WINDOW - 1; ++k)
+        if (k == j) h0 = w.h[k], h1 = w.h[k + 1];
+    slope = (h1 - h0) * INV_STEP;
+    g = h0 + slope * (x - (float)(w.j0 + j) * TERRAIN_STEP);
+}
 }  // namespace biped
 
 template <class T>
@@ -81,7 +124,8 @@ constexpr bool above(int link, int k) { return (ANCESTRY<T> >> (8 * link + k)) &
 // q'' for joint torques tau; sets the bits of `contact` for the contact points that touch
 template <class T>
 PSIM_FN void accelerations(const PlanarParams* __restrict__ P, const float (&q)[T::L + 2], const float (&qd)[T::L + 2],
-                                              const float (&tau)[T::L], float (&qdd)[T::L + 2], unsigned& contact) {
+                                              const float (&tau)[T::L], float (&qdd)[T::L + 2], unsigned& contact,
+                                              const biped::TerrainWindow& terrain) {
     constexpr int L = T::L, n = L + 2;
     float ang[L], ox[L], oy[L], w[L], sn[L], cs[L];
 #pragma unroll
@@ -157,7 +201,14 @@ PSIM_FN void accelerations(const PlanarParams* __restrict__ P, const float (&q)[
         const int link = unpack(T::CL, c);
         const float px = ox[link] + cs[link] * P->c_local[c][0] - sn[link] * P->c_local[c][1];
         const float py = oy[link] + sn[link] * P->c_local[c][0] + cs[link] * P->c_local[c][1];
-        if (py < 0.f) {
+        // the ground under the point: flat at y = 0, or the walker's terrain (normal (-slope, 1) / r, tangent (1, slope) / r)
+        float g = 0.f, slope = 0.f, ir = 1.f;             // ir = 1 / |(-slope, 1)|
+        if (T::TASK == 1 && terrain.on) {
+            biped::ground(terrain, px, g, slope);
+            ir = PSIM_RSQRT(1.f + slope * slope);
+        }
+        const float pen = (g - py) * ir;
+        if (pen > 0.f) {
             float vx = qd[0], vy = qd[1];
 #pragma unroll
             for (int k = 0; k < L; ++k)
@@ -165,13 +216,15 @@ PSIM_FN void accelerations(const PlanarParams* __restrict__ P, const float (&q)[
                     vx -= (py - oy[k]) * qd[2 + k];
                     vy += (px - ox[k]) * qd[2 + k];
                 }
-            const float fn = fmaxf(0.f, -P->k_contact * py - P->c_contact * vy);
-            const float ft = fminf(P->mu * fn, fmaxf(-P->mu * fn, -P->c_friction * vx));
-            Q[0] += ft;
-            Q[1] += fn;
+            const float vn = (vy - slope * vx) * ir, vt = (vx + slope * vy) * ir;
+            const float fn = fmaxf(0.f, P->k_contact * pen - P->c_contact * vn);
+            const float ft = fminf(P->mu * fn, fmaxf(-P->mu * fn, -P->c_friction * vt));
+            const float fx = (ft - slope * fn) * ir, fy = (fn + slope * ft) * ir;
+            Q[0] += fx;
+            Q[1] += fy;
 #pragma unroll
             for (int k = 0; k < L; ++k)
-                if (above<T>(link, k)) Q[2 + k] += -(py - oy[k]) * ft + (px - ox[k]) * fn;
+                if (above<T>(link, k)) Q[2 + k] += -(py - oy[k]) * fx + (px - ox[k]) * fy;
             contact |= 1u << c;
         }
     }
@@ -209,8 +262,10 @@ PSIM_FN void accelerations(const PlanarParams* __restrict__ P, const float (&q)[
 }
 
 template <class T>
-PSIM_FN void observe(const float (&q)[T::L + 2], const float (&qd)[T::L + 2], float c0, float c1, float* __restrict__ o) {
+PSIM_FN void observe(const float (&q)[T::L + 2], const float (&qd)[T::L + 2], float c0, float c1, float* __restrict__ o,
+                     const float* __restrict__ terrain, int ts) {
     constexpr int n = T::L + 2;
+    constexpr float LIDAR_SIN[10] = LIDAR_SIN_TABLE, LIDAR_COS[10] = LIDAR_COS_TABLE;
     if (T::TASK == 0) {
 #pragma unroll
         for (int i = 1; i < n; ++i) o[i - 1] = q[i];
@@ -224,8 +279,45 @@ PSIM_FN void observe(const float (&q)[T::L + 2], const float (&qd)[T::L + 2], fl
         o[3] = 0.3f * qd[1] * (400.f / SCALE) / FPS;
         o[4] = q[3], o[5] = qd[3] / SPEED_HIP, o[6] = q[4] + 1.f, o[7] = qd[4] / SPEED_KNEE, o[8] = c0;
         o[9] = q[5], o[10] = qd[5] / SPEED_HIP, o[11] = q[6] + 1.f, o[12] = qd[6] / SPEED_KNEE, o[13] = c1;
+        // 10 lidar rays from the hull, 0 .. 1.35 rad from straight down towards the front (world axes): the fraction of
+        // the range at which each meets the ground.  The 14 heights the rays can reach are read once; the first
+        // segment also covers what lies behind its left end, the last one what lies beyond the track.
+        if (terrain == nullptr) {
 #pragma unroll
-        for (int k = 0; k < 10; ++k) o[14 + k] = fminf(1.f, fmaxf(0.f, q[1] / (cosf(1.5f * k / 10.f) * LIDAR_RANGE)));
+            for (int i = 0; i < 10; ++i) o[14 + i] = fminf(1.f, fmaxf(0.f, q[1] / (LIDAR_COS[i] * LIDAR_RANGE)));
+        } else {
+            int j0 = (int)floorf(q[0] * INV_STEP);
+            j0 = j0 < 0 ? 0 : (j0 > TERRAIN_LENGTH - 2 ? TERRAIN_LENGTH - 2 : j0);
+            float hgt[LIDAR_SEGMENTS + 1];
+#pragma unroll
+            for (int k = 0; k <= LIDAR_SEGMENTS; ++k) {
+                const int j = j0 + k;
+                hgt[k] = terrain[(size_t)(j > TERRAIN_LENGTH - 1 ? TERRAIN_LENGTH - 1 : j) * ts];
+            }
+            const int last = TERRAIN_LENGTH - 2 - j0;       // segments k >= last are the track's final one, repeated
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                const float dx = LIDAR_SIN[i] * LIDAR_RANGE, dy = -LIDAR_COS[i] * LIDAR_RANGE;
+                float best = 1.f;
+                // ray i spans at most dx / TERRAIN_STEP segments beyond the one under the hull (a compile-time bound)
+                const int reach = (int)(LIDAR_SIN[i] * LIDAR_RANGE * INV_STEP) + 2;
+#pragma unroll
+                for (int k = 0; k < LIDAR_SEGMENTS; ++k) {
+                    if (k >= reach) continue;
+                    const bool tail = k >= last;            // clamped onto the final segment of the track
+                    const float h0 = tail ? terrain[(size_t)(TERRAIN_LENGTH - 2) * ts] : hgt[k];
+                    const float h1 = tail ? terrain[(size_t)(TERRAIN_LENGTH - 1) * ts] : hgt[k + 1];
+                    const float xj = (float)(tail ? TERRAIN_LENGTH - 2 : j0 + k) * TERRAIN_STEP;
+                    const float sl = (h1 - h0) * INV_STEP;
+                    const float t = (q[1] - h0 - sl * (q[0] - xj)) * PSIM_RCP(sl * dx - dy);
+                    const float xh = q[0] + t * dx;
+                    const bool lo_ok = (k == 0 || j0 + k == 0) || xh >= xj;
+                    const bool hi_ok = tail || xh <= xj + TERRAIN_STEP;
+                    if (t >= 0.f && lo_ok && hi_ok && t < best) best = t;
+                }
+                o[14 + i] = fminf(1.f, fmaxf(0.f, best));
+            }
+        }
     }
 }
 
@@ -233,7 +325,8 @@ PSIM_FN void observe(const float (&q)[T::L + 2], const float (&qd)[T::L + 2], fl
 // `raw` points at the T::A action components of this environment.
 template <class T>
 PSIM_FN void advance(const PlanarParams* __restrict__ P, float (&q)[T::L + 2], float (&qd)[T::L + 2], const float* __restrict__ raw,
-                     float& c0, float& c1, float& prev, float& rew, bool& term) {
+                     float& c0, float& c1, float& prev, float& rew, bool& term, const float* __restrict__ terrain,
+                     int terrain_stride) {
     constexpr int L = T::L, n = L + 2;
     float act[T::A], raw2 = 0.f, abs_sum = 0.f;
 #pragma unroll
@@ -246,6 +339,9 @@ PSIM_FN void advance(const PlanarParams* __restrict__ P, float (&q)[T::L + 2], f
     const float x0 = q[0];
     const float h = P->dt / (float)P->substeps;
     unsigned contact = 0u;
+    biped::TerrainWindow window;
+    window.on = false;
+    if (T::TASK == 1) biped::load_window(terrain, terrain_stride, q[0], window);
     for (int sub = 0; sub < P->substeps; ++sub) {
         float tau[L], qdd[n];
         tau[0] = 0.f;
@@ -262,7 +358,7 @@ PSIM_FN void advance(const PlanarParams* __restrict__ P, float (&q)[T::L + 2], f
                 tau[1 + j] = fminf(limit, fmaxf(-limit, SERVO_GAIN * MOTORS_TORQUE * (speed * sg - qd[3 + j]) / speed));
             }
         }
-        accelerations<T>(P, q, qd, tau, qdd, contact);
+        accelerations<T>(P, q, qd, tau, qdd, contact, window);
 #pragma unroll
         for (int i = 0; i < n; ++i) {
             qd[i] += h * qdd[i];

@@ -20,6 +20,7 @@
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Tuple
 
 import numpy as np
@@ -140,7 +141,8 @@ class DevicePlanar(_DeviceEnvBase):
     from the host class, so the two cannot drift apart."""
     STRIDE = 24
 
-    def __init__(self, host_cls, num_envs: int, device="cuda", seed: int = 0, time_limit: int = 1000, limit_terminal: bool = True):
+    def __init__(self, host_cls, num_envs: int, device="cuda", seed: int = 0, time_limit: int = 1000, limit_terminal: bool = True,
+                 terrain: bool = True):
         host = host_cls(1)
         super().__init__(num_envs, host.state_dim, host.action_dim, device, seed, time_limit)
         from .native_planar import planar_params
@@ -148,12 +150,18 @@ class DevicePlanar(_DeviceEnvBase):
         self.state = torch.zeros(self.E, self.STRIDE, dtype=torch.float32, device=self.device)
         self.limit_terminal = bool(limit_terminal)
         self.n = host.model.n
+        # the walker's ground: [200][E] heights (sample-major: coalesced over the environments of a wavefront), drawn by
+        # the kernel at every reset (terrain=False: all zero)
+        self.terrain = torch.zeros(200, self.E, dtype=torch.float32, device=self.device) if self.kind == 3 else None
+        self.hilly = bool(terrain)
         self._params_dev = torch.frombuffer(bytearray(bytes(self.params)), dtype=torch.uint8).to(self.device)
 
     def _args(self, init: int) -> H.PlanarEnvArgs:
         a = H.PlanarEnvArgs()
         self._fill(a, init)
         a.P, a.kind = self._params_dev.data_ptr(), self.kind
+        flat = self.terrain is None or os.environ.get("D4PG_WALKER_FLAT_GROUND") == "1"      # diagnostic: the flat-ground path
+        a.terrain, a.hilly = (None if flat else self.terrain.data_ptr()), int(self.hilly)
         a.limit_terminal, a.reward_scale = int(self.limit_terminal), self.reward_scale
         return a
 

@@ -107,7 +107,8 @@ def host_step_fn():
                 raise RuntimeError(f"PlanarParams: {C.sizeof(H.PlanarParams)} bytes in ops/hip.py, {size()} in csrc/planar_host.cpp")
             fn = lib.d4pg_planar_host_step
             fn.restype = C.c_int
-            fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+            fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                           C.c_void_p]
             _fn = fn
         except (OSError, AttributeError):
             _fn = False
@@ -129,15 +130,18 @@ class _NativeStep:
         self._rew32 = np.zeros(E, np.float32)
         self._term = np.zeros(E, np.uint8)
         self._n = self.model.n
+        self._terrain32 = np.zeros((E, 200), np.float32) if self._kind == 3 else None
 
     def _step(self, actions: np.ndarray):
         n, st, sim = self._n, self._state, self.sim
         st[:, :n], st[:, QD0:QD0 + n] = sim.q, sim.qd
         if self._kind == 3:
             st[:, FLAG0:FLAG0 + 2], st[:, PREV] = sim.contact_on[:, :2], self.prev_shaping
+            self._terrain32[:] = sim.terrain
         self._act32[:] = actions
         rc = self._fn(C.addressof(self._params), self._kind, self.num_envs, st.ctypes.data, self._act32.ctypes.data,
-                      self.action_dim, self._obs32.ctypes.data, self._rew32.ctypes.data, self._term.ctypes.data)
+                      self.action_dim, self._obs32.ctypes.data, self._rew32.ctypes.data, self._term.ctypes.data,
+                      self._terrain32.ctypes.data if self._terrain32 is not None else None)
         if rc != 0:
             raise RuntimeError(f"d4pg_planar_host_step failed ({rc})")
         sim.q[:], sim.qd[:] = st[:, :n], st[:, QD0:QD0 + n]

@@ -20,7 +20,9 @@ termination rules, episode limits, units — with link dimensions and masses tak
 geometry (capsule volumes x density 1000 for the MuJoCo bodies, polygon areas x the fixture densities for the
 walker).  Same tasks, own simulator: returns are comparable in kind (a Hopper that hops forward collects about
 its forward speed + 1 per step, a walker that reaches the far end about 300), not trajectory by trajectory, and
-the walker's ground is flat (no random hills; its 10 lidar readings are the exact ray / ground intersections).
+the walker's ground is the gym task's grass (a damped random walk of the slope after a flat start pad; contact
+forces along the local normal and tangent; the 10 lidar readings are the exact ray / ground intersections), without the
+obstacles of the hardcore variant.
 """
 from __future__ import annotations
 
@@ -75,6 +77,19 @@ class PlanarSim:
         self.q = np.zeros((self.E, model.n))
         self.qd = np.zeros((self.E, model.n))
         self.contact_on = np.zeros((self.E, len(model.contacts)), bool)
+        self.terrain: Optional[np.ndarray] = None        # [E, J] ground heights at x = j * terrain_step (None: flat, y = 0)
+        self.terrain_step = 1.0
+
+    def ground(self, x: np.ndarray, env: Optional[np.ndarray] = None):
+        """Height and slope of the ground under ``x [E]`` (piecewise linear between the terrain's samples)."""
+        if self.terrain is None:
+            return np.zeros_like(x), np.zeros_like(x)
+        J = self.terrain.shape[1]
+        rows = np.arange(self.terrain.shape[0]) if env is None else env
+        j = np.clip(np.floor(x / self.terrain_step), 0, J - 2).astype(np.int64)
+        h0, h1 = self.terrain[rows, j], self.terrain[rows, j + 1]
+        slope = (h1 - h0) / self.terrain_step
+        return h0 + slope * (x - j * self.terrain_step), slope
 
     # ---- kinematics -----------------------------------------------------------------------------
     def frames(self, q: Optional[np.ndarray] = None):
@@ -158,11 +173,14 @@ class PlanarSim:
             p = self._world(ang[:, link], org[:, link], local)
             J = self._jacobian(link, p, org)
             v = np.einsum("eki,ei->ek", J, qd)
-            pen = -p[:, 1]
+            g, slope = self.ground(p[:, 0])
+            r = np.sqrt(1.0 + slope * slope)                   # ground normal (-slope, 1) / r, tangent (1, slope) / r
+            pen = (g - p[:, 1]) / r
             on = pen > 0.0
-            fn = np.where(on, np.maximum(0.0, m.k_contact * pen - m.c_contact * v[:, 1]), 0.0)
-            ft = np.where(on, np.clip(-m.c_friction * v[:, 0], -m.mu * fn, m.mu * fn), 0.0)
-            Q += np.einsum("eki,ek->ei", J, np.stack([ft, fn], axis=1))
+            vn, vt = (v[:, 1] - slope * v[:, 0]) / r, (v[:, 0] + slope * v[:, 1]) / r
+            fn = np.where(on, np.maximum(0.0, m.k_contact * pen - m.c_contact * vn), 0.0)
+            ft = np.where(on, np.clip(-m.c_friction * vt, -m.mu * fn, m.mu * fn), 0.0)
+            Q += np.einsum("eki,ek->ei", J, np.stack([(ft - slope * fn) / r, (fn + slope * ft) / r], axis=1))
             self.contact_on[:, ci] |= on
         return np.linalg.solve(M, Q[..., None])[..., 0]
 
@@ -244,10 +262,13 @@ class BipedalWalkerVec(VecEnv):
     START_X = 14 / 30.0 * 20 / 2
     SERVO_GAIN = 6.0
     SUBSTEPS = 8
+    TERRAIN_STEP, TERRAIN_LENGTH, TERRAIN_STARTPAD, LIDAR_SEGMENTS = 14 / 30.0, 200, 20, 13
 
-    def __init__(self, num_envs: int = 1, seed=None, time_limit: int = 1600, env_name: str = "BipedalWalker-v2"):
+    def __init__(self, num_envs: int = 1, seed=None, time_limit: int = 1600, env_name: str = "BipedalWalker-v2",
+                 terrain: bool = True):
         super().__init__(env_name, num_envs, 24, 4, -1.0, 1.0, seed)
         self.time_limit = int(time_limit)
+        self.hilly = bool(terrain)
         hull_m, hull_i = 5.42, 2.2                       # polygon area 976 px^2 / 900 x density 5
         th_m = self.LEG_W * self.LEG_H * 1.0
         sh_m = 0.8 * self.LEG_W * self.LEG_H * 1.0
@@ -263,9 +284,53 @@ class BipedalWalkerVec(VecEnv):
         self.model = Model(links, contacts, gravity=10.0, k_contact=8000.0, c_contact=150.0, c_friction=150.0, mu=2.5,
                            k_limit=600.0, c_limit=6.0)
         self.sim = PlanarSim(self.model, self.num_envs)
+        self.sim.terrain = np.zeros((self.num_envs, self.TERRAIN_LENGTH))
+        self.sim.terrain_step = self.TERRAIN_STEP
         self.t = np.zeros(self.num_envs, np.int64)
         self.prev_shaping = np.zeros(self.num_envs)
         self._act = np.zeros((self.num_envs, 4))
+
+    def _new_terrain(self, e: int) -> None:
+        """The gym task's grass: a flat start pad, then heights that follow a damped random walk of the slope
+        (``velocity = 0.8 velocity + 0.01 sign(-y) + U(-1, 1) / 30`` per 0.467 of track)."""
+        h = self.sim.terrain[e]
+        h[:] = 0.0
+        if not self.hilly:
+            return
+        noise = self.rng.uniform(-1.0, 1.0, self.TERRAIN_LENGTH) / self.SCALE
+        y = velocity = 0.0
+        for i in range(self.TERRAIN_LENGTH):
+            velocity = 0.8 * velocity + 0.01 * np.sign(-y)
+            if i > self.TERRAIN_STARTPAD:
+                velocity += noise[i]
+            y += velocity
+            h[i] = y
+
+    def lidar(self, idx=slice(None)) -> np.ndarray:
+        """Fractions ``[E, 10]`` of the lidar range at which the 10 rays from the hull (0 to 1.35 rad from straight
+        down, towards the front, world axes) meet the ground; 1 where they do not."""
+        sim = self.sim
+        q = np.atleast_2d(sim.q[idx])
+        ter = np.atleast_2d(sim.terrain[idx])
+        E, J, step = q.shape[0], ter.shape[1], self.TERRAIN_STEP
+        ang = 1.5 * np.arange(10) / 10.0
+        dx, dy = np.sin(ang) * self.LIDAR_RANGE, -np.cos(ang) * self.LIDAR_RANGE             # [10]
+        x0, y0 = q[:, 0], q[:, 1]
+        j0 = np.clip(np.floor(x0 / step), 0, J - 2).astype(np.int64)
+        best = np.ones((E, 10))
+        rows = np.arange(E)
+        for k in range(self.LIDAR_SEGMENTS):
+            j = np.clip(j0 + k, 0, J - 2)
+            xj = j * step
+            h0, h1 = ter[rows, j], ter[rows, j + 1]
+            s = (h1 - h0) / step
+            t = (y0 - h0 - s * (x0 - xj))[:, None] / (s[:, None] * dx[None, :] - dy[None, :])
+            xh = x0[:, None] + t * dx[None, :]
+            lo = np.where((j == 0) | (k == 0), -np.inf, xj)[:, None]          # the first segment also covers what lies behind
+            hi = np.where(j == J - 2, np.inf, xj + step)[:, None]
+            ok = (t >= 0.0) & (xh >= lo) & (xh <= hi)
+            best = np.where(ok & (t < best), t, best)
+        return np.clip(best, 0.0, 1.0)
 
     def _torques(self, sim: PlanarSim) -> np.ndarray:
         a = self._act
@@ -279,8 +344,7 @@ class BipedalWalkerVec(VecEnv):
     def _obs(self, idx=slice(None)) -> np.ndarray:
         q, qd, on = self.sim.q[idx], self.sim.qd[idx], self.sim.contact_on[idx]
         q, qd, on = np.atleast_2d(q), np.atleast_2d(qd), np.atleast_2d(on)
-        ang = 1.5 * np.arange(10) / 10.0
-        lidar = np.clip(q[:, 1:2] / (np.cos(ang)[None, :] * self.LIDAR_RANGE), 0.0, 1.0)
+        lidar = self.lidar(idx)
         o = np.concatenate([
             q[:, 2:3], 2.0 * qd[:, 2:3] / self.FPS, 0.3 * qd[:, 0:1] * (600 / self.SCALE) / self.FPS,
             0.3 * qd[:, 1:2] * (400 / self.SCALE) / self.FPS,
@@ -298,6 +362,7 @@ class BipedalWalkerVec(VecEnv):
 
     def _reset_env(self, e: int) -> np.ndarray:
         s = self.sim
+        self._new_terrain(e)
         s.q[e] = 0.0
         s.qd[e] = 0.0
         s.q[e, 0] = self.START_X

@@ -314,9 +314,9 @@ class PlanarParams(C.Structure):
 
 class PlanarEnvArgs(C.Structure):
     _fields_ = [("P", vp), ("state", vp), ("t", vp), ("ep_return", vp), ("action", vp), ("obs", vp), ("next_obs", vp),
-                ("reward", vp), ("done", vp), ("trunc", vp), ("noise", vp), ("stats", vp), ("counter", vp),
+                ("reward", vp), ("done", vp), ("trunc", vp), ("noise", vp), ("stats", vp), ("counter", vp), ("terrain", vp),
                 ("seed", C.c_ulonglong), ("E", C.c_int), ("ld_act", C.c_int), ("time_limit", C.c_int), ("init", C.c_int),
-                ("limit_terminal", C.c_int), ("kind", C.c_int), ("reward_scale", C.c_float)]
+                ("limit_terminal", C.c_int), ("kind", C.c_int), ("reward_scale", C.c_float), ("hilly", C.c_int)]
 
 
 class AntParams(C.Structure):

@@ -127,7 +127,7 @@ def test_walker_and_cheetah_rules():
 
 
 def test_bipedal_walker_observation_reward_and_terminals():
-    env = BipedalWalkerVec(3, seed=6)
+    env = BipedalWalkerVec(3, seed=6, terrain=False)
     obs = env.reset().astype(np.float64)
     q = env.sim.q
     np.testing.assert_allclose(obs[:, 0], q[:, 2], atol=1e-7)                                 # hull angle
@@ -197,6 +197,7 @@ def test_device_planar_follows_the_host_simulator(cls, name, S, A):
             host.sim.contact_on[:] = False
             host.sim.contact_on[:, :2] = st[:, 18:20] > 0.5
             host.prev_shaping[:] = st[:, 20]
+            host.sim.terrain[:] = dev.terrain.cpu().double().numpy().T           # the device keeps it sample-major
     follow()
     np.testing.assert_allclose(obs.cpu().numpy(), host._obs(), rtol=1e-5, atol=1e-6)
     nobs, rew, done, trunc = (torch.zeros(E, S, device="cuda"), torch.zeros(E, device="cuda"),
@@ -251,6 +252,7 @@ def test_host_runtime_simulator_follows_the_numpy_oracle(cls, name, S, A):
         nat.sim.contact_on[:] = ref.sim.contact_on
         if cls is BipedalWalkerVec:
             nat.prev_shaping[:] = ref.prev_shaping
+            nat.sim.terrain[:] = ref.sim.terrain
         o_r, r_r, d_r = ref._step(act)
         o_n, r_n, d_n = nat._step(act)
         close = np.all(np.abs(o_n - o_r) <= 2e-3 + 2e-3 * np.abs(o_r), axis=1)
@@ -273,3 +275,47 @@ def test_host_runtime_simulator_follows_the_numpy_oracle(cls, name, S, A):
             env.reset_env(e)
             dones += 1
     assert dones >= 8
+
+
+def test_bipedal_walker_terrain_and_lidar():
+    """The gym task's grass: a flat start pad, gentle random hills after it; contact follows the ground; the lidar
+    readings are the exact ray / ground intersections (checked against a brute-force march along the rays)."""
+    env = BipedalWalkerVec(4, seed=0)
+    env.reset()
+    ter, step = env.sim.terrain, env.TERRAIN_STEP
+    assert not ter[:, :21].any() and np.abs(ter[:, 21:]).max() > 0.1 and np.abs(ter).max() < 2.5
+    assert np.abs(np.diff(ter, axis=1)).max() / step < 0.5 and not np.array_equal(ter[0], ter[1])
+    g, s = env.sim.ground(np.array([25.3, 40.0, 60.1, 80.7]))
+    j = np.floor(np.array([25.3, 40.0, 60.1, 80.7]) / step).astype(int)
+    np.testing.assert_allclose(s, (ter[np.arange(4), j + 1] - ter[np.arange(4), j]) / step)
+    env.sim.q[:, 0] = [25.3, 40.0, 60.1, 80.7]
+    env.sim.q[:, 1] = g + 1.9
+    got = env.lidar()
+    ang = 1.5 * np.arange(10) / 10
+    for e in range(4):
+        for i in range(10):
+            ts = np.linspace(0.0, 1.0, 100001)
+            xs = env.sim.q[e, 0] + ts * np.sin(ang[i]) * env.LIDAR_RANGE
+            ys = env.sim.q[e, 1] - ts * np.cos(ang[i]) * env.LIDAR_RANGE
+            gs, _ = env.sim.ground(xs, env=np.full(xs.shape, e))
+            hit = np.nonzero(ys <= gs)[0]
+            assert abs((ts[hit[0]] if len(hit) else 1.0) - got[e, i]) < 3e-4
+    # a walker set down on a slope rests ON the slope: feet within the contact springs' sag of the local ground
+    env = BipedalWalkerVec(2, seed=3)
+    env.reset()
+    x = 50.0
+    g, s = env.sim.ground(np.array([x, x]))
+    env.sim.q[:, 0], env.sim.q[:, 1] = x, g + 2 * env.LEG_H - env.LEG_DOWN + 0.02
+    env.prev_shaping[:] = env._shaping()
+    touched = np.zeros(2, bool)
+    for _ in range(12):
+        env.step(np.zeros((2, 4)))
+        touched |= env.sim.contact_on[:, :2].any(axis=1)
+        for link in (2, 4):                                      # no foot ever sinks through the local ground
+            foot = env.sim.point(link, (0.0, -env.LEG_H))
+            gf, _ = env.sim.ground(foot[:, 0])
+            assert (foot[:, 1] - gf > -0.03).all()
+    assert touched.all()
+    new = create_env_wrapper(default_config(env="BipedalWalker-v2", model="d4pg", device="cpu"), 2, seed=1)
+    new.reset()
+    assert np.abs(new.sim.terrain).max() > 0.05                  # the factory builds the hilly task
