@@ -8,7 +8,8 @@ reduced coordinates ``q = (x, y, root angle, joint angles...)``:
 * mass matrix ``M(q) = sum_i m_i Jv_i' Jv_i + I_i Jw_i' Jw_i`` (+ rotor inertia on the joint diagonal) from the
   links' centre-of-mass Jacobians, bias forces from the centripetal accelerations of the chain, gravity, joint
   damping, joint limits as stiff springs;
-* contact points (feet, heels, the torso) against flat ground as spring-dampers with a friction cone
+* contact points (feet, heels, the torso) against the ground (flat, or a piecewise-linear terrain with the force
+  along its local normal and tangent) as spring-dampers with a friction cone
   (``|f_t| <= mu f_n``, viscous inside it);
 * actuators: torque ``gear x action`` (MuJoCo tasks) or a torque-limited speed servo (the walker's Box2D motors:
   target speed ``sign(a) x SPEED``, torque limit ``80 |a|``);
