@@ -73,14 +73,7 @@ constexpr float TERRAIN_STEP = 14.f / 30.f, INV_STEP = 30.f / 14.f;
 #define LIDAR_SIN_TABLE {0.f, 0.14943813f, 0.29552021f, 0.43496553f, 0.56464247f, 0.68163876f, 0.78332691f, 0.86742323f, 0.93203909f, 0.97572336f}
 #define LIDAR_COS_TABLE {1.f, 0.98877108f, 0.95533649f, 0.90044710f, 0.82533561f, 0.73168887f, 0.62160997f, 0.49757105f, 0.36235775f, 0.21900669f}
 constexpr int TERRAIN_LENGTH = 200, TERRAIN_STARTPAD = 20, LIDAR_SEGMENTS = 13;
-// height and slope of the ground under x: piecewise linear between the samples terrain[j] at x = j * TERRAIN_STEP
-PSIM_FN void ground(const float* __restrict__ terrain, int ts, float x, float& g, float& slope) {
-    int j = (int)floorf(x / TERRAIN_STEP);
-    j = j < 0 ? 0 : (j > TERRAIN_LENGTH - 2 ? TERRAIN_LENGTH - 2 : j);
-    const float h0 = terrain[(size_t)j * ts], h1 = terrain[(size_t)(j + 1) * ts];
-    slope = (h1 - h0) / TERRAIN_STEP;
-    g = h0 + slope * (x - (float)j * TERRAIN_STEP);
-}
+// the ground is piecewise linear between the samples terrain[j] at x = j * TERRAIN_STEP
 // The stretch of ground the walker can touch during one step (feet and hull corners stay within 2.5 of the hull's
 // centre), read ONCE per step: inside the sub-steps a lookup is a chain of selects on registers instead of two
 // dependent memory loads on the critical path of a latency-bound thread.

@@ -20,7 +20,6 @@
 """
 from __future__ import annotations
 
-import os
 from typing import Optional, Tuple
 
 import numpy as np
@@ -160,8 +159,7 @@ class DevicePlanar(_DeviceEnvBase):
         a = H.PlanarEnvArgs()
         self._fill(a, init)
         a.P, a.kind = self._params_dev.data_ptr(), self.kind
-        flat = self.terrain is None or os.environ.get("D4PG_WALKER_FLAT_GROUND") == "1"      # diagnostic: the flat-ground path
-        a.terrain, a.hilly = (None if flat else self.terrain.data_ptr()), int(self.hilly)
+        a.terrain, a.hilly = (self.terrain.data_ptr() if self.terrain is not None else None), int(self.hilly)
         a.limit_terminal, a.reward_scale = int(self.limit_terminal), self.reward_scale
         return a
 
