@@ -223,7 +223,7 @@ def draw_segments(segments, w: int = 300, h: int = 200, ground_y: Optional[int] 
     return img
 
 
-def render_planar(sim: "PlanarSim", e: int, ends, view: float = 4.0, w: int = 300, h: int = 200) -> np.ndarray:
+def render_planar(sim: "PlanarSim", e: int, ends, view: float = 4.0, w: int = 300, h: int = 200, row: float = 0.55) -> np.ndarray:
     """Stick figure of environment ``e``, camera on the root: every link from its hinge to ``ends[link]`` (a point in
     the link's frame) and on to the hinges of its children."""
     ang, org = sim.frames()
@@ -231,7 +231,7 @@ def render_planar(sim: "PlanarSim", e: int, ends, view: float = 4.0, w: int = 30
     cx, cy = sim.q[e, 0], max(0.35 * view * h / w, sim.q[e, 1])
 
     def px(p):
-        return (w / 2 + (p[0] - cx) * scale, h * 0.55 - (p[1] - cy) * scale)
+        return (w / 2 + (p[0] - cx) * scale, h * row - (p[1] - cy) * scale)
     palette = ((128, 102, 230), (230, 180, 60), (90, 200, 120), (230, 110, 110))
     segs = []
     for i, l in enumerate(sim.m.links):
@@ -240,7 +240,14 @@ def render_planar(sim: "PlanarSim", e: int, ends, view: float = 4.0, w: int = 30
         for j, c in enumerate(sim.m.links):
             if c.parent == i:
                 segs.append((px(org[e, i]), px(org[e, j]), palette[i % len(palette)]))
-    return draw_segments(segs, w, h, ground_y=int(px((0.0, 0.0))[1]))
+    if sim.terrain is None:
+        return draw_segments(segs, w, h, ground_y=int(px((0.0, 0.0))[1]))
+    step = sim.terrain_step                                  # the ground as the polyline it is
+    j_lo = max(0, int((cx - view / 2) / step))
+    j_hi = min(sim.terrain.shape[1] - 2, int((cx + view / 2) / step) + 1)
+    for j in range(j_lo, j_hi + 1):
+        segs.append((px((j * step, sim.terrain[e, j])), px(((j + 1) * step, sim.terrain[e, j + 1])), (90, 90, 90)))
+    return draw_segments(segs, w, h)
 
 
 def _capsule(length: float, radius: float, density: float = 1000.0):
@@ -359,7 +366,7 @@ class BipedalWalkerVec(VecEnv):
 
     def render(self, e: int = 0) -> np.ndarray:
         ends = [(34 / 30.0, 0.0)] + [(0.0, -self.LEG_H)] * 4
-        return render_planar(self.sim, e, ends, view=8.0)
+        return render_planar(self.sim, e, ends, view=8.0, row=0.4)
 
     def _reset_env(self, e: int) -> np.ndarray:
         s = self.sim
