@@ -90,8 +90,9 @@ class GreedyEvaluator:
 
 
 def train_on_device(model: str = "d4pg", core: str = "fp32", updates: int = 20_000, seed: int = 0,
-                             eval_every: int = 1000, envs: int = 8, segment: int = 32, eval_envs: int = 64,
-                             warmup_segments: int = 8, device="cuda", env: str = "Pendulum-v0", **overrides) -> Dict:
+                    eval_every: int = 1000, envs: int = 8, segment: int = 32, eval_envs: int = 64,
+                    warmup_segments: int = 8, device="cuda", env: str = "Pendulum-v0", return_actor: bool = False,
+                    **overrides) -> Dict:
     """Train on a device-resident environment (the pendulum by default; any id ``envs/device_envs.py::make_device_env``
     knows: the lunar lander, the articulated-body tasks, ...); returns the evaluation curve and summary numbers.
 
@@ -145,7 +146,8 @@ def train_on_device(model: str = "d4pg", core: str = "fp32", updates: int = 20_0
     rets = [r for _, r in curve]
     first: Optional[int] = next((s for s, r in curve if r > -300.0), None)
     m = c.read_metrics()
-    return {"env": env, "model": model, "core": core, "core_class": type(c).__name__, "seed": seed, "updates": step,
+    extra = {"actor_flat": c.target.actor_flat().detach().cpu().numpy()} if return_actor else {}      # the TARGET policy's weights
+    return {**extra, "env": env, "model": model, "core": core, "core_class": type(c).__name__, "seed": seed, "updates": step,
             "env_steps": ro.env_steps, "wall_s": round(wall, 1), "curve": [(s, round(r, 1)) for s, r in curve],
             "initial_return": round(rets[0], 1), "final_return": round(rets[-1], 1),
             "last5_mean_return": round(sum(rets[-5:]) / len(rets[-5:]), 1), "best_return": round(max(rets), 1),
