@@ -118,28 +118,28 @@ replay_device: hbm
 compute_dtype: fp32       # reference precision: fused row-local pipeline on exact f32 MFMA (the default); 'bf16' = the same
                           # pipeline with bf16 MFMA operands, 1.5x (batch 256) to 3x (batch 4096) faster, opt-in
 """,
-    "walker2d_d4pg_dp8.yml": """# Walker2d-shape D4PG, 8 data-parallel learners (one per MI355X) over RCCL, replicated update on the all-gathered batch.
+    "walker2d_d4pg_dp8.yml": """# Walker2d D4PG, 8 data-parallel learners (one per MI355X) over RCCL, replicated update on the all-gathered batch.
 env: Walker2d-v2
 model: d4pg
 num_agents: 3
 num_learners: 8
 batch_size: 256          # per learner rank
-v_min: 0.0
-v_max: 5000.0
+v_min: 0.0               # the range discounted returns take on the native task (gamma 0.99)
+v_max: 400.0
 device: cuda
 replay_device: hbm
 compute_dtype: fp32       # reference precision: fused row-local pipeline on exact f32 MFMA (the default); 'bf16' = the same
                           # pipeline with bf16 MFMA operands, 1.5x (batch 256) to 3x (batch 4096) faster, opt-in
 """,
-    "half_cheetah_d4pg_dp8.yml": """# HalfCheetah-shape D4PG, 8 data-parallel learners.
+    "half_cheetah_d4pg_dp8.yml": """# HalfCheetah D4PG, 8 data-parallel learners.
 env: HalfCheetah-v2
 model: d4pg
 num_agents: 3
 num_learners: 8
 batch_size: 256
 n_step_returns: 5
-v_min: 0.0
-v_max: 10000.0
+v_min: -50.0             # the range discounted returns take on the native task (gamma 0.99)
+v_max: 600.0
 device: cuda
 replay_device: hbm
 compute_dtype: fp32       # reference precision: fused row-local pipeline on exact f32 MFMA (the default); 'bf16' = the same
