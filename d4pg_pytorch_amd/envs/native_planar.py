@@ -1,9 +1,10 @@
-"""The planar articulated-body tasks stepped by the C++ host runtime (``csrc/planar_host.cpp``).
+"""The articulated-body tasks (planar: Hopper, Walker2d, HalfCheetah, BipedalWalker; 3-D: Ant) stepped by the C++ host
+runtime (``csrc/planar_host.cpp``).
 
-``envs/planar.py`` is the simulator written out in numpy (fp64; the oracle the other two are tested against) and
-runs 1 - 3 k environment steps/s per process.  The classes here keep its task definition, reset logic and state
+``envs/planar.py`` and ``envs/spatial.py`` are the simulators written out in numpy (fp64; the oracles the other two
+builds are tested against) and run 1 - 3 k environment steps/s per process.  The classes here keep its task definition, reset logic and state
 (``sim.q``, ``sim.qd``) and replace the step by one call into the host library, which is built from the same
-source as the device kernels (``csrc/planar_sim.h``, fp32): two orders of magnitude more steps per second for the
+source as the device kernels (``csrc/planar_sim.h``, ``csrc/ant_sim.h``, fp32): two orders of magnitude more steps per second for the
 CPU explorer processes of the reference's topology (``models/agent.py:60-145`` steps a Box2D / MuJoCo simulator
 there).  ``create_env_wrapper`` picks these classes whenever the host library is built.
 """
