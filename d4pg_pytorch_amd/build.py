@@ -60,8 +60,8 @@ FUSED_PARTS = {"fused.hip": (-1, 13, 4, 8, 0), "fused32.hip": (-1, 13, 4, 8)}
 #: is miscompiled at -O2 / -O3 by hipcc 7.2 (wrong accelerations on the device; the -O1 build and the host build of
 #: the same source agree with the numpy simulator) and -O1 is also the fastest build of it (290 registers, 84 us per
 #: step of 4096 ants against 125 us for the -O3 build in link order); tests/test_spatial_env.py checks the result.
-#: (planar_env.hip at -O1: 10 - 20 % faster launched stand-alone, 34.4 against 33.9 us per Walker2d step inside the
-#: captured rollout: left at -O3.)
+#: (planar_env.hip at -O1: 10 - 20 % faster launched stand-alone; inside the captured rollout Walker2d and the
+#: walker are unchanged (68.8, 111 us per step of 4096 environments) and HalfCheetah gains 12 % (85 -> 75 us): left at -O3.)
 OPT_LEVEL = {"ant_env.hip": "-O1"}
 
 
