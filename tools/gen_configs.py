@@ -193,13 +193,80 @@ num_steps_train: 50000
 """,
     "walker2d_d4pg_device_explorers.yml": """# Walker2d D4PG with the explorers ON the learner's GPU (csrc/planar_env.hip: the articulated-body simulator as a
 # kernel, one thread per environment); the GPU exploiter plays the host simulator (envs/planar.py) with the
-# learner's target policy, read through HIP IPC.  Same for Hopper-v2, HalfCheetah-v2 (v_min -50, v_max 600) and
-# BipedalWalker-v2 (v_min -100, v_max 300, max_ep_length 1600): --set env=... state_dim=... action_dim=...
+# learner's target policy, read through HIP IPC.  (Hopper, HalfCheetah, BipedalWalker, Ant: the files next to this one.)
 env: Walker2d-v2
 model: d4pg
 num_agents: 1             # the exploiter only
 v_min: 0.0                # the range discounted returns take (gamma 0.99, reward per step up to about 4)
 v_max: 400.0
+device: cuda
+replay_device: hbm
+gpu_rollout_envs: 256     # environments stepped on the GPU
+gpu_rollout_segment: 32   # steps per captured rollout segment
+gpu_rollout_interval: 32  # learner updates between two segments (256 env steps per update)
+num_steps_train: 200000
+""",
+    "bipedal_d4pg_device_explorers.yml": """# BipedalWalker-v2 D4PG with the explorers ON the learner's GPU (the simulator as a kernel, one thread per environment); the
+# GPU exploiter plays the host simulator with the learner's target policy, read through HIP IPC.
+env: BipedalWalker-v2
+model: d4pg
+state_dim: 24
+action_dim: 4
+num_agents: 1             # the exploiter only
+max_ep_length: 1600
+v_min: -100.0             # the range discounted returns take (gamma 0.99)
+v_max: 300.0
+device: cuda
+replay_device: hbm
+gpu_rollout_envs: 256     # environments stepped on the GPU
+gpu_rollout_segment: 32   # steps per captured rollout segment
+gpu_rollout_interval: 32  # learner updates between two segments (256 env steps per update)
+num_steps_train: 200000
+""",
+    "half_cheetah_d4pg_device_explorers.yml": """# HalfCheetah-v2 D4PG with the explorers ON the learner's GPU (the simulator as a kernel, one thread per environment); the
+# GPU exploiter plays the host simulator with the learner's target policy, read through HIP IPC.
+env: HalfCheetah-v2
+model: d4pg
+state_dim: 17
+action_dim: 6
+num_agents: 1             # the exploiter only
+max_ep_length: 1000
+v_min: -50.0             # the range discounted returns take (gamma 0.99)
+v_max: 600.0
+device: cuda
+replay_device: hbm
+gpu_rollout_envs: 256     # environments stepped on the GPU
+gpu_rollout_segment: 32   # steps per captured rollout segment
+gpu_rollout_interval: 32  # learner updates between two segments (256 env steps per update)
+num_steps_train: 200000
+""",
+    "hopper_d4pg_device_explorers.yml": """# Hopper-v2 D4PG with the explorers ON the learner's GPU (the simulator as a kernel, one thread per environment); the
+# GPU exploiter plays the host simulator with the learner's target policy, read through HIP IPC.
+env: Hopper-v2
+model: d4pg
+state_dim: 11
+action_dim: 3
+num_agents: 1             # the exploiter only
+max_ep_length: 1000
+v_min: 0.0             # the range discounted returns take (gamma 0.99)
+v_max: 400.0
+device: cuda
+replay_device: hbm
+gpu_rollout_envs: 256     # environments stepped on the GPU
+gpu_rollout_segment: 32   # steps per captured rollout segment
+gpu_rollout_interval: 32  # learner updates between two segments (256 env steps per update)
+num_steps_train: 200000
+""",
+    "ant_d4pg_device_explorers.yml": """# Ant-v2 D4PG with the explorers ON the learner's GPU (the simulator as a kernel, one thread per environment); the
+# GPU exploiter plays the host simulator with the learner's target policy, read through HIP IPC.
+env: Ant-v2
+model: d4pg
+state_dim: 111
+action_dim: 8
+num_agents: 1             # the exploiter only
+max_ep_length: 1000
+v_min: 0.0             # the range discounted returns take (gamma 0.99)
+v_max: 300.0
 device: cuda
 replay_device: hbm
 gpu_rollout_envs: 256     # environments stepped on the GPU
