@@ -1,7 +1,7 @@
 """One step of the device ant (the library named by D4PG_HIP_LIB) against the C++ host build, and the time of a step
 of 4096 environments: the check used on builds of csrc/ant_env.hip with another loop order / optimisation level."""
 import sys, time
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))))
 import numpy as np, torch
 from d4pg_pytorch_amd.envs.device_envs import DeviceAnt
 from d4pg_pytorch_amd.envs.native_planar import NativeAntVec

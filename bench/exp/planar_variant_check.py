@@ -1,6 +1,6 @@
 """Time of one device step of 4096 environments of each planar task for the library named by D4PG_HIP_LIB."""
 import sys, time
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))))
 import torch
 from d4pg_pytorch_amd.envs import planar
 from d4pg_pytorch_amd.envs.device_envs import DevicePlanar
