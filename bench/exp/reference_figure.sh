@@ -8,7 +8,7 @@ O=gpurun_out/figure
 mkdir -p $O
 one() {
   name=$1; cfg=$2; shift; shift
-  timeout -k 10 600 python train.py --config $cfg --set device=cuda results_path=$O/$name envs_per_agent=8 updates_per_env_step=0.125 num_episode_save=100000 save_reward_threshold=1000000 "$@" > $O/$name.log 2>&1 || { tail -20 $O/$name.log; return 1; }
+  timeout -k 10 600 python train.py --config $cfg --set device=cuda results_path=$O/$name envs_per_agent=8 updates_per_env_step=0.125 num_episode_save=100000 save_reward_threshold=1000000 max_env_steps_per_agent=1000000000 "$@" > $O/$name.log 2>&1 || { tail -20 $O/$name.log; return 1; }
   run=$(ls -d $O/$name/* | tail -1)
   python - <<PY
 import json, sys
