@@ -11,7 +11,10 @@ Run ``python -m d4pg_pytorch_amd.build`` or call :func:`build_all`.
 """
 from __future__ import annotations
 
+import hashlib
+import json
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -32,11 +35,57 @@ def _run(cmd: List[str]) -> None:
         raise RuntimeError(f"command failed: {' '.join(cmd)}\n{proc.stdout}")
 
 
-def _stale(target: str, sources: List[str]) -> bool:
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(s) > t for s in sources)
+def _read(path: str) -> bytes:
+    with open(path, "rb") as f:
+        return f.read()
+
+
+_INCLUDE = re.compile(rb'^\s*#\s*include\s*"([^"]+)"', re.M)
+
+
+def _closure(src: str) -> List[str]:
+    """`src` and every header of csrc/ it includes, directly or not (quoted includes only)."""
+    seen, todo = [], [src]
+    while todo:
+        f = todo.pop()
+        if f in seen or not os.path.exists(f):
+            continue
+        seen.append(f)
+        for m in _INCLUDE.finditer(_read(f)):
+            todo.append(os.path.join(os.path.dirname(f), m.group(1).decode()))
+    return sorted(seen)
+
+
+def _digest(cmd: List[str], files: List[str]) -> str:
+    """What an output depends on: the command line (flags, optimisation level, defines) and the CONTENT of
+    its inputs.  Modification times say nothing after a fresh checkout or a copy to another machine."""
+    h = hashlib.sha256()
+    h.update("\0".join(os.path.basename(c) if os.sep in c else c for c in cmd).encode())
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0" + hashlib.sha256(_read(f)).digest())
+    return h.hexdigest()
+
+
+def _manifest_path(target: str) -> str:
+    return target + ".manifest.json"
+
+
+def _recorded(target: str) -> str:
+    """Digest stored next to `target` when it was built, '' if either is missing."""
+    try:
+        with open(_manifest_path(target)) as f:
+            return json.load(f)["digest"] if os.path.exists(target) else ""
+    except (OSError, ValueError, KeyError):
+        return ""
+
+
+def _record(target: str, digest: str, parts: dict) -> None:
+    with open(_manifest_path(target), "w") as f:
+        json.dump({"digest": digest, "parts": parts}, f, indent=1, sort_keys=True)
+
+
+#: what the last build_all() did, for the caller to print ("reused" or "compiled N objects" per library)
+LAST_BUILD: dict = {}
 
 
 def _hipcc() -> str:
@@ -65,64 +114,81 @@ FUSED_PARTS = {"fused.hip": (-1, 13, 4, 8, 0), "fused32.hip": (-1, 13, 4, 8)}
 OPT_LEVEL = {"ant_env.hip": "-O1"}
 
 
-def build_hip(force: bool = False, verbose: bool = False) -> str:
-    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    headers = [os.path.join(CSRC, h) for h in ("common.h", "loss_dev.h", "replay_dev.h", "phase_common.h", "mlp32_dev.h", "planar_sim.h", "ant_sim.h")]
-    deps = srcs + headers
-    if not force and not _stale(HIP_LIB, deps):
-        return HIP_LIB
+def _hip_units(stamps: bool):
+    """(source, part, object path, command) of every translation unit of the HIP library."""
     objdir = os.path.join(CSRC, "build")
-    os.makedirs(objdir, exist_ok=True)
-    objs = []
     hipcc = _hipcc()
-    jobs = []
-    stamps = bool(os.environ.get("D4PG_STAMPS"))    # diagnostic build: per-layer clock stamps (bench/stamps.py)
-    for s in srcs:
-        base = os.path.basename(s)
-        # fused.hip is built as five objects, one per hidden width of the phase kernels plus the main one
-        # (see the head of the file); the stamp build keeps it in one piece
-        parts = FUSED_PARTS[base] if (base in FUSED_PARTS and not (stamps and base == "fused.hip")) else (None,)
+    units = []
+    for name in HIP_SOURCES:
+        s = os.path.join(CSRC, name)
+        # fused.hip / fused32.hip are built as one object per hidden width of the phase kernels plus the main one
+        # (see the head of the files); the stamp build keeps fused.hip in one piece
+        parts = FUSED_PARTS[name] if (name in FUSED_PARTS and not (stamps and name == "fused.hip")) else (None,)
         for part in parts:
-            o = os.path.join(objdir, base + ("" if part is None else f".part{part}") + ".o")
-            if force or _stale(o, [s] + headers):
-                cmd = [hipcc, OPT_LEVEL.get(base, "-O3"), f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-c", s, "-o", o]
-                if part is not None:
-                    cmd.insert(1, f"-DD4PG_KSH_PART={part}")
-                if stamps:
-                    cmd.insert(1, "-DD4PG_STAMPS")
-                if verbose:
-                    print(" ".join(cmd), flush=True)
-                jobs.append(cmd)
-            objs.append(o)
+            o = os.path.join(objdir, name + ("" if part is None else f".part{part}") + ".o")
+            cmd = [hipcc, OPT_LEVEL.get(name, "-O3"), f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-c", s, "-o", o]
+            if part is not None:
+                cmd.insert(1, f"-DD4PG_KSH_PART={part}")
+            if stamps:
+                cmd.insert(1, "-DD4PG_STAMPS")
+            units.append((s, part, o, cmd))
+    return units
+
+
+def build_hip(force: bool = False, verbose: bool = False) -> str:
+    stamps = bool(os.environ.get("D4PG_STAMPS"))    # diagnostic build: per-layer clock stamps (bench/stamps.py)
+    units = _hip_units(stamps)
+    want = {os.path.basename(o): _digest(cmd, _closure(s)) for s, _, o, cmd in units}
+    lib_digest = hashlib.sha256(json.dumps(want, sort_keys=True).encode()).hexdigest()
+    if not force and _recorded(HIP_LIB) == lib_digest:
+        LAST_BUILD["hip"] = "reused (digest of sources + flags matches the library's manifest)"
+        return HIP_LIB
+    os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
+    jobs = []
+    for s, _, o, cmd in units:
+        if force or _recorded(o) != want[os.path.basename(o)]:
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            jobs.append((o, cmd))
     if jobs:        # the translation units are independent: compile them side by side
         from concurrent.futures import ThreadPoolExecutor
         workers = max(1, min(len(jobs), int(os.environ.get("MAX_JOBS", "0")) or (os.cpu_count() or 1), 8))
         with ThreadPoolExecutor(max_workers=workers) as pool:
-            list(pool.map(_run, jobs))
+            list(pool.map(_run, [cmd for _, cmd in jobs]))
+        for o, _ in jobs:
+            _record(o, want[os.path.basename(o)], {})
     tl = torch_lib_dir()
     tmp = HIP_LIB + ".tmp"
-    _run(["g++", "-shared", "-o", tmp] + objs + [f"-L{tl}", "-l:libamdhip64.so"])
+    _run(["g++", "-shared", "-o", tmp] + [o for _, _, o, _ in units] + [f"-L{tl}", "-l:libamdhip64.so"])
     os.replace(tmp, HIP_LIB)
+    _record(HIP_LIB, lib_digest, want)
+    LAST_BUILD["hip"] = f"compiled {len(jobs)} of {len(units)} objects, linked"
     return HIP_LIB
 
 
 def build_host(force: bool = False, verbose: bool = False) -> str:
     srcs = [os.path.join(CSRC, s) for s in HOST_SOURCES]
-    if not force and not _stale(HOST_LIB, srcs + [os.path.join(CSRC, "planar_sim.h"), os.path.join(CSRC, "ant_sim.h")]):
-        return HOST_LIB
     tmp = HOST_LIB + ".tmp"
     cmd = ["g++", "-O3", "-march=x86-64-v3", "-fPIC", "-shared", "-std=c++17", "-pthread", "-fopenmp-simd"] + srcs + \
           ["-o", tmp, "-lrt"]
+    digest = _digest(cmd, sorted({f for s in srcs for f in _closure(s)}))
+    if not force and _recorded(HOST_LIB) == digest:
+        LAST_BUILD["host"] = "reused (digest of sources + flags matches the library's manifest)"
+        return HOST_LIB
     if verbose:
         print(" ".join(cmd), flush=True)
     _run(cmd)
     os.replace(tmp, HOST_LIB)
+    _record(HOST_LIB, digest, {})
+    LAST_BUILD["host"] = f"compiled {len(srcs)} sources, linked"
     return HOST_LIB
 
 
 def build_all(force: bool = False, verbose: bool = False) -> None:
     build_host(force, verbose)
     build_hip(force, verbose)
+    if verbose:
+        print(f"build: host runtime {LAST_BUILD['host']}; HIP kernels {LAST_BUILD['hip']}", flush=True)
 
 
 if __name__ == "__main__":

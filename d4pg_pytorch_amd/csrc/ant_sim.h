@@ -19,7 +19,11 @@
 #else
 #include <cmath>
 #define ASIM_FN static inline
+#ifdef ASIM_NO_SINCOS
+#define ASIM_SINCOS(x, s, c) (*(s) = sinf(x), *(c) = cosf(x))
+#else
 #define ASIM_SINCOS(x, s, c) sincosf((x), (s), (c))
+#endif
 #define ASIM_FINITE(x) std::isfinite(x)
 #endif
 
@@ -31,6 +35,9 @@ struct AntParams {
     int substeps, n_links, n_contacts, pad_;
     int parent[9], c_link[13];            // the host model's topology: checked at launch against the compiled one
 };
+#ifndef ASIM_LOOP_BODY_BEGIN
+#define ASIM_LOOP_BODY_BEGIN(P)
+#endif
 namespace ant {
 constexpr int L = 9, N = 14, C = 13, STRIDE = 32, S = 111;
 struct V3 {
@@ -88,7 +95,11 @@ ASIM_FN V3 column(const Frames& F, int link, int col, V3 p) {
 // u' for hinge torques tau; `wrench` [L][6] receives (moment about the link's centre of mass, force) of the ground
 ASIM_FN void accelerations(const AntParams* __restrict__ P, const float (&pos)[3], const float (&quat)[4],
                                               const float (&qj)[8], const float (&u)[N], const float (&tau)[8], float h,
-                                              float (&ud)[N], float (&wrench)[L][6]) {
+                                              float (&ud)[N], float (&wrench)[L][6]
+#ifdef ASIM_DEBUG          // bench/exp/ant_rootcause: the system before it is factorised
+                                              , float* dbg = nullptr
+#endif
+) {
     Frames F;
     {
         const float w = quat[0], x = quat[1], y = quat[2], z = quat[3];
@@ -242,6 +253,17 @@ ASIM_FN void accelerations(const AntParams* __restrict__ P, const float (&pos)[3
             }
         }
     }
+#ifdef ASIM_DEBUG
+    if (dbg != nullptr) {
+        int n = 0;
+#pragma unroll
+        for (int a = 0; a < N; ++a)
+#pragma unroll
+            for (int b = 0; b <= a; ++b) dbg[n++] = M[a][b];
+#pragma unroll
+        for (int a = 0; a < N; ++a) dbg[n++] = Q[a];
+    }
+#endif
     // Cholesky M = G G' in the lower triangle, then two triangular solves
 #pragma unroll
     for (int j = 0; j < N; ++j) {
@@ -318,6 +340,7 @@ ASIM_FN void advance(const AntParams* __restrict__ P, float (&pos)[3], float (&q
     const float h = P->dt / (float)P->substeps;
     for (int sub = 0; sub < P->substeps; ++sub) {
         float ud[N];
+        ASIM_LOOP_BODY_BEGIN(P)
         accelerations(P, pos, quat, qj, u, tau, h, ud, wrench);
 #pragma unroll
         for (int i = 0; i < N; ++i) u[i] += h * ud[i];
