@@ -95,6 +95,9 @@ def parse_args():
                     help="time the unfused eager-PyTorch update (reference op sequence) instead")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--tile-rows", default="auto", choices=["auto", "4", "8", "16", "32"])
+    ap.add_argument("--mfma", default="auto", choices=["auto", "4x4", "16x16"],
+                    help="fp32 phase kernels: v_mfma_f32_4x4x1 (compiled hidden widths) or v_mfma_f32_16x16x4 (any width)")
+    ap.add_argument("--hidden", type=int, default=400, help="dense_size (400: the reference's)")
     ap.add_argument("--dp-mode", default="both", choices=["both", "replicated", "grad_allreduce"],
                     help="data-parallel scheme for N > 1 (see the module docstring)")
     ap.add_argument("--chunk", type=int, default=0,
@@ -155,10 +158,10 @@ def main() -> None:
               "HalfCheetah-v2": (0.0, 10000.0), "BipedalWalker-v2": (-100.0, 300.0),
               "Ant-v2": (0.0, 4000.0), "Pendulum-v0": (-1000.0, 0.0)}.get(env, (-100.0, 100.0))
     cfg = default_config(env=env, model=args.model, batch_size=args.batch, n_step_returns=5,
-                         dense_size=400, num_atoms=51, v_min=vrange[0], v_max=vrange[1],
+                         dense_size=args.hidden, num_atoms=51, v_min=vrange[0], v_max=vrange[1],
                          device="cuda", replay_mem_size=args.replay_size,
                          replay_memory_prioritized=int(args.per), use_hip_graph=not args.no_graph,
-                         compute_dtype=args.dtype, phase_tile_rows=args.tile_rows,
+                         compute_dtype=args.dtype, phase_tile_rows=args.tile_rows, phase_mfma=args.mfma,
                          num_steps_train=max(1, args.steps * max(1, repeats) + args.warmup),
                          fused_learner="torch" if args.baseline else ("layers" if args.layers else "auto"), random_seed=2019)
     if args.chunk > 0:
@@ -233,9 +236,10 @@ def main() -> None:
                                   (type(core).__name__ + ":" +
                                    {"HipCoreF32": "hip-fused-rowlocal-fp32-mfma", "HipCoreBf16": "hip-fused-rowlocal-bf16",
                                     "HipCore": "hip-per-layer-fp32-mfma"}.get(type(core).__name__, "?")
+                                   + ("-16x16x4" if getattr(core, "wide", False) else "")
                                    + ("" if args.no_graph else "+hipgraph")),
-                "config": {"model": "%s %s (S=%d, A=%d, H=400%s)" % (
-                               env, args.model.upper(), S, A, ", 51 atoms" if args.model == "d4pg" else ""),
+                "config": {"model": "%s %s (S=%d, A=%d, H=%d%s)" % (
+                               env, args.model.upper(), S, A, args.hidden, ", 51 atoms" if args.model == "d4pg" else ""),
                            "global_batch": args.batch * world, "seq_len": 1,
                            "n_step": 5, "replay": "per-hbm-sumtree" if args.per else "uniform-hbm",
                            "parallelism": "dp%d" % world + {

@@ -1,18 +1,29 @@
 // One environment step (advance() of csrc/ant_sim.h: the sub-step loop around accelerations()) for the states of
 // states_contact.bin, as csrc/ant_env.hip's kernel calls it.  Writes state (29) + reward (1) per environment.
-// Variants are chosen on the command line of the build (run_step.sh): optimisation level, -DLOOP_OPAQUE (the
-// parameter pointer passes through an empty asm in every sub-step, so no load from it can be hoisted out of the
-// loop), and the backend's spill options.
+// Variants are chosen on the command line of the build (build_step.sh): optimisation level, -DWITH_RESTRICT
+// (`__restrict__` on the parameter block and the action pointer of advance() / accelerations()), -DHOIST (without the empty
+// asm through which csrc/ant_sim.h passes the parameter pointer in every sub-step, so that no load from it can be
+// hoisted out of the loop), and the backend's spill options.
 #include <hip/hip_runtime.h>
-#ifdef LOOP_OPAQUE
-#define ASIM_LOOP_BODY_BEGIN(P) asm volatile("" : "+s"(P));
+#ifdef WITH_RESTRICT        // the qualifier that csrc/ant_sim.h no longer carries
+#define ASIM_RESTRICT __restrict__
+#endif
+#ifdef DUMP_SYSTEM          // also writes the first sub-step's system (M, Q) and solution behind the 30 state values
+#define ASIM_DEBUG
+#endif
+#ifdef HOIST               // without the empty asm that keeps the parameter loads inside the sub-step loop
+#define ASIM_LOOP_BODY_BEGIN(P)
 #endif
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 #include "ant_sim.h"
 
+#ifdef DUMP_SYSTEM
+constexpr int OUT = 30 + 133;
+#else
 constexpr int OUT = 30;
+#endif
 
 __global__ __launch_bounds__(64) void step_kernel(const AntParams* Pin, const float* st_all, const float* act, float* out, int E) {
     using namespace ant;
@@ -35,8 +46,12 @@ __global__ __launch_bounds__(64) void step_kernel(const AntParams* Pin, const fl
         for (int k = 0; k < 6; ++k) wrench[i][k] = 0.f;
     float rew;
     bool term;
-    advance(P, pos, quat, qj, u, act + (size_t)e * 8, wrench, rew, term);
     float* o = out + (size_t)e * OUT;
+#ifdef DUMP_SYSTEM
+    advance(P, pos, quat, qj, u, act + (size_t)e * 8, wrench, rew, term, o + 30);
+#else
+    advance(P, pos, quat, qj, u, act + (size_t)e * 8, wrench, rew, term);
+#endif
 #pragma unroll
     for (int i = 0; i < 3; ++i) o[i] = pos[i];
 #pragma unroll

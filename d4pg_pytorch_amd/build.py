@@ -101,17 +101,16 @@ def torch_lib_dir() -> str:
 
 
 #: translation units of csrc/fused.hip / csrc/fused32.hip: -1 = C API + weight gradients, the others one
-#: hidden width each (0 = the run-time-width variant, bf16 pipeline only)
-FUSED_PARTS = {"fused.hip": (-1, 13, 4, 8, 0), "fused32.hip": (-1, 13, 4, 8)}
+#: hidden width each (0 = the run-time-width variants: bf16 pipeline, and the 16x16x4 path of the fp32 pipeline)
+FUSED_PARTS = {"fused.hip": (-1, 13, 4, 8, 0), "fused32.hip": (-1, 13, 4, 8, 0)}
 
 
-#: optimisation level per source where it is not -O3.  ant_env.hip: the fully unrolled 14 x 14 system in leg order
-#: is miscompiled at -O2 / -O3 by hipcc 7.2 (wrong accelerations on the device; the -O1 build and the host build of
-#: the same source agree with the numpy simulator) and -O1 is also the fastest build of it (290 registers, 84 us per
-#: step of 4096 ants against 125 us for the -O3 build in link order); tests/test_spatial_env.py checks the result.
-#: (planar_env.hip at -O1: 10 - 20 % faster launched stand-alone; inside the captured rollout Walker2d and the
-#: walker are unchanged (68.8, 111 us per step of 4096 environments) and HalfCheetah gains 12 % (85 -> 75 us): left at -O3.)
-OPT_LEVEL = {"ant_env.hip": "-O1"}
+#: optimisation level per source where it is not -O3.  ant_env.hip: -O1 is the FASTEST build of the fully unrolled
+#: 14 x 14 system (85.6 us per step of 4096 ants against 98.8 at -O2 and 98.9 at -O3: 290 registers against 450), and
+#: since the parameter pointer passes through an empty asm in every sub-step all three levels are correct (csrc/ant_sim.h
+#: has the cause of the wrong -O2 / -O3 builds of earlier revisions; tests/test_spatial_env.py holds the device build
+#: to the host simulator step by step at whatever level is built).
+OPT_LEVEL: dict = {"ant_env.hip": "-O1"}
 
 
 def _hip_units(stamps: bool):

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(64) void ant_step_kernel(const AntEnvArgs a) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned long long ctr = *a.counter;
     if (e >= a.E) return;
-    const AntParams* __restrict__ P = a.P;
+    const AntParams* P = a.P;      // (not restrict-qualified: csrc/ant_sim.h)
     float* st = a.state + (size_t)e * STRIDE;
     float pos[3], quat[4], qj[8], u[N], wrench[L][6];
 #pragma unroll

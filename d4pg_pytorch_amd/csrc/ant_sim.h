@@ -35,8 +35,29 @@ struct AntParams {
     int substeps, n_links, n_contacts, pad_;
     int parent[9], c_link[13];            // the host model's topology: checked at launch against the compiled one
 };
+// hipcc 7.2, gfx950, -O2 / -O3: when the ~100 loads from the parameter block are hoisted out of the sub-step loop of
+// advance() (which the optimiser does whenever it can prove them invariant: `__restrict__` on the pointer, or a
+// pointer that comes straight out of the kernel arguments), the kernel needs all 106 scalar registers plus spills
+// for them across a body of 450 vector registers, and the 14 x 14 system comes out wrong from the FIRST sub-step on:
+// entries such as M[3][1] read 0.0197 or 2.4e15 for 0.0527, and every state with ground contact ends non-finite.
+// What it is not: undefined behaviour in this source (host builds at -O0 / -O3 agree bit for bit and are clean under
+// ASan, UBSan and MSan; no -Wall -Wextra -Wuninitialized finding), floating-point contraction (-ffp-contract=off),
+// type-based aliasing (-fno-strict-aliasing), loop unrolling (-fno-unroll-loops) or where spills go
+// (-amdgpu-spill-sgpr-to-vgpr=false, -amdgpu-spill-vgpr-to-agpr=false): none of these changes the wrong result.
+// accelerations() called once outside a loop is right at every level; the loop is right at -O1, and at -O3 as soon
+// as the loads cannot leave it.  So the pointer passes through an empty asm at the top of every sub-step (34 scalar
+// registers instead of 106, no scalar spills), the qualifier is gone, and tests/test_spatial_env.py holds the device
+// build to the host simulator step by step.  Drivers, variants and their outputs: bench/exp/ant_rootcause/,
+// profiles/ant_rootcause/.
+#ifndef ASIM_RESTRICT
+#define ASIM_RESTRICT
+#endif
 #ifndef ASIM_LOOP_BODY_BEGIN
+#if defined(__HIPCC__)
+#define ASIM_LOOP_BODY_BEGIN(P) asm volatile("" : "+s"(P));
+#else
 #define ASIM_LOOP_BODY_BEGIN(P)
+#endif
 #endif
 namespace ant {
 constexpr int L = 9, N = 14, C = 13, STRIDE = 32, S = 111;
@@ -93,7 +114,7 @@ ASIM_FN V3 column(const Frames& F, int link, int col, V3 p) {
 }
 
 // u' for hinge torques tau; `wrench` [L][6] receives (moment about the link's centre of mass, force) of the ground
-ASIM_FN void accelerations(const AntParams* __restrict__ P, const float (&pos)[3], const float (&quat)[4],
+ASIM_FN void accelerations(const AntParams* ASIM_RESTRICT P, const float (&pos)[3], const float (&quat)[4],
                                               const float (&qj)[8], const float (&u)[N], const float (&tau)[8], float h,
                                               float (&ud)[N], float (&wrench)[L][6]
 #ifdef ASIM_DEBUG          // bench/exp/ant_rootcause: the system before it is factorised
@@ -136,9 +157,6 @@ ASIM_FN void accelerations(const AntParams* __restrict__ P, const float (&pos)[3
         for (int k = 0; k < 6; ++k) wrench[i][k] = 0.f;
     // the torso (g = 0), then one leg after the other: a leg's frames, Jacobian columns and contact points are dead
     // before the next leg starts, which shortens the live ranges of everything but M, Q and the torso's frame.
-    // (Device builds of this order at -O2 / -O3 with hipcc 7.2 return wrong accelerations; -O1 and the host build
-    // agree with the numpy simulator: csrc/ant_env.hip is built at -O1, see build.py, and tests/test_spatial_env.py
-    // holds the device build to the host simulator step by step.)
 #pragma unroll
     for (int g = 0; g < 5; ++g) {
         const int first = g == 0 ? 0 : 2 * g - 1, last = g == 0 ? 0 : 2 * g;
@@ -298,7 +316,7 @@ ASIM_FN void accelerations(const AntParams* __restrict__ P, const float (&pos)[3
 }
 
 ASIM_FN void observe(const float (&pos)[3], const float (&quat)[4], const float (&qj)[8], const float (&u)[N],
-                                        const float (&wrench)[L][6], float* __restrict__ o) {
+                                        const float (&wrench)[L][6], float* o) {
     o[0] = pos[2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) o[1 + i] = quat[i];
@@ -327,8 +345,13 @@ ASIM_FN void observe(const float (&pos)[3], const float (&quat)[4], const float 
 
 // One environment step without the episode bookkeeping: sub-steps, then reward and termination of the task.
 // `raw` points at the 8 action components of this environment.
-ASIM_FN void advance(const AntParams* __restrict__ P, float (&pos)[3], float (&quat)[4], float (&qj)[8], float (&u)[N],
-                     const float* __restrict__ raw, float (&wrench)[L][6], float& rew, bool& term) {
+ASIM_FN void advance(const AntParams* ASIM_RESTRICT P_in, float (&pos)[3], float (&quat)[4], float (&qj)[8], float (&u)[N],
+                     const float* ASIM_RESTRICT raw, float (&wrench)[L][6], float& rew, bool& term
+#ifdef ASIM_DEBUG
+                     , float* dbg = nullptr
+#endif
+) {
+    const AntParams* P = P_in;
     float tau[8], act2 = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -341,7 +364,13 @@ ASIM_FN void advance(const AntParams* __restrict__ P, float (&pos)[3], float (&q
     for (int sub = 0; sub < P->substeps; ++sub) {
         float ud[N];
         ASIM_LOOP_BODY_BEGIN(P)
+#ifdef ASIM_DEBUG
+        accelerations(P, pos, quat, qj, u, tau, h, ud, wrench, sub == 0 ? dbg : nullptr);
+        if (sub == 0 && dbg != nullptr)
+            for (int i = 0; i < N; ++i) dbg[119 + i] = ud[i];
+#else
         accelerations(P, pos, quat, qj, u, tau, h, ud, wrench);
+#endif
 #pragma unroll
         for (int i = 0; i < N; ++i) u[i] += h * ud[i];
 #pragma unroll

@@ -20,6 +20,7 @@
 #include "replay_dev.h"
 #include "phase_common.h"
 #include "mlp32_dev.h"
+#include "mlp16_dev.h"
 
 // Compiled once per hidden width (build.py, -DD4PG_KSH_PART=<KSH>), like csrc/fused.hip: the unit of one
 // width holds the phase kernels for that width, the main unit (-1) the C API and the weight gradients.
@@ -124,6 +125,51 @@ struct Chain32 {
         layer32<NW32, MT, KSN, true>(SLOT == 0 ? t0 : t1, A, lda, L, red, epi, pre, lst);
     }
 };
+
+// KSH == 0: the 16x16x4 path of csrc/mlp16_dev.h (any widths, known at run time; tiles of 8 or 16 rows, MT = 2 / 4).
+// The same interface, so the roles below are written once.
+template <int MT, int KSN>
+struct Chain32<MT, 0, KSN> {
+    static_assert(MT == 2 || MT == 4, "the 16x16x4 path takes tiles of 8 or 16 rows");
+    Pre16 t0, t1;
+    float* red;
+    int wave, lane;
+    __device__ __forceinline__ Chain32(float* red_) : red(red_) {
+        lane = threadIdx.x & 63;
+        wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    }
+    template <int SLOT>
+    __device__ __forceinline__ void prefetch_h(const LayerW32& L) {
+        (SLOT == 0 ? t0 : t1) = fetch_pass16<NW32>(L, wave, lane, 0, true);
+    }
+    template <int SLOT>
+    __device__ __forceinline__ void prefetch_s(const LayerW32& L) {
+        (SLOT == 0 ? t0 : t1) = fetch_pass16<NW32>(L, wave, lane, 0, true);
+    }
+    template <int SLOT>
+    __device__ __forceinline__ void prefetch_n(const LayerW32& L) {
+        (SLOT == 0 ? t0 : t1) = fetch_pass16<NW32>(L, wave, lane, 0, true);
+    }
+    template <int SLOT>
+    __device__ __forceinline__ void prefetch_n_if(const LayerW32& L, bool run) {
+        (SLOT == 0 ? t0 : t1) = fetch_pass16<NW32>(L, wave, lane, 0, run);
+    }
+    template <int SLOT, typename F, typename P>
+    __device__ __forceinline__ void hidden(const float* A, int lda, const LayerW32& L, F&& epi, P&& pre, int = -1) {
+        layer16<NW32, 4 * MT>(SLOT == 0 ? t0 : t1, A, lda, L, red, epi, pre);
+    }
+    template <int SLOT, typename F, typename P>
+    __device__ __forceinline__ void split(const float* A, int lda, const LayerW32& L, F&& epi, P&& pre) {
+        layer16<NW32, 4 * MT>(SLOT == 0 ? t0 : t1, A, lda, L, red, epi, pre);
+    }
+    template <int SLOT, typename F, typename P>
+    __device__ __forceinline__ void narrow(const float* A, int lda, const LayerW32& L, F&& epi, P&& pre, int = -1) {
+        layer16<NW32, 4 * MT>(SLOT == 0 ? t0 : t1, A, lda, L, red, epi, pre);
+    }
+};
+
+// floats of LDS for the K-slice partial sums of a workgroup
+__host__ __device__ constexpr int red_floats32(int mt, bool wide) { return wide ? (NW32 - 1) * 256 : (NW32 - 1) * mt * 256; }
 
 // ---- LDS / stash helpers ------------------------------------------------------------------------
 // 4 consecutive rows of one column -> LDS (consecutive lanes = consecutive columns: no bank conflicts)
@@ -240,7 +286,8 @@ struct ActorPhaseArgs32 {
     const SampleArgs* smp;   // ahead.mode == 3: how the NEXT batch is drawn (prioritised replay)
 };
 
-__host__ __device__ __forceinline__ bool critic_red_aliased(const PhaseDims& d) { return (NW32 - 1) * 64 <= d.ldh; }
+// (never on the 16x16x4 path: there a layer of any kind may be dealt out in K-slices)
+__host__ __device__ __forceinline__ bool critic_red_aliased(const PhaseDims& d, bool wide) { return !wide && (NW32 - 1) * 64 <= d.ldh; }
 
 // ---- loss rows: one wave per row ------------------------------------------------------------------
 struct CriticRowsOut {
@@ -329,7 +376,7 @@ __device__ __forceinline__ void actor_forward_role(const CriticPhaseArgs32& a, i
     float* xin = (float*)carve(M * d.ldx * 4);     // [s | pi(s)]
     float* bufA = (float*)carve(M * d.ldh * 4);    // h1
     float* bufB = (float*)carve(M * d.ldh * 4);    // h2
-    float* red = (float*)carve((NW32 - 1) * MT * 256 * 4);
+    float* red = (float*)carve(red_floats32(MT, KSH == 0) * 4);
     Chain32<MT, KSH, KSN> ch(red);
     ch.template prefetch_n<0>(f.af[0]);
     // (the epilogue lambdas capture scalars only: a closure that holds a copy of the kernel arguments
@@ -458,7 +505,7 @@ __global__ __launch_bounds__(64 * NW32) void critic_phase32_kernel(const CriticP
     // The K-slice partial sums of the three output layers (a', target logits, logits) go where bufA is:
     // its tile (an input of the hidden layer before) is dead whenever one of them runs.  Only when they
     // fit; a 16-row tile of a 400-wide network needs every byte of the LDS.
-    float* red = critic_red_aliased(d) ? bufA : (float*)carve((NW32 - 1) * MT * 256 * 4);
+    float* red = critic_red_aliased(d, KSH == 0) ? bufA : (float*)carve(red_floats32(MT, KSH == 0) * 4);
     Chain32<MT, KSH, KSN> ch(red);
     ch.template prefetch_n<0>(a.ta[0]);
     const int SA = d.S + d.A;
@@ -597,7 +644,7 @@ __device__ __forceinline__ void critic_ahead_role(const ActorPhaseArgs32& a, int
     float* bufC = (float*)carve(M * d.ldh * 4);
     float* bufD = (float*)carve(M * d.ldh * 4);
     float* lg = (float*)carve(M * d.nop * 4);
-    float* red = (float*)carve((NW32 - 1) * MT * 256 * 4);
+    float* red = (float*)carve(red_floats32(MT, KSH == 0) * 4);
     Chain32<MT, KSH, KSN> ch(red);
     ch.template prefetch_n<0>(a.cf[0]);
     zero_tail(bufC, d.ldh, M, d.H);
@@ -692,7 +739,7 @@ __global__ __launch_bounds__(64 * NW32) void actor_phase32_kernel(const ActorPha
     float* dlg = (float*)carve(M * d.ldd * 4);
     float* dab = (float*)carve(M * d.lda_ * 4);
     float* lg_o = (float*)carve(M * d.nop * 4);
-    float* red = (float*)carve((NW32 - 1) * MT * 256 * 4);
+    float* red = (float*)carve(red_floats32(MT, KSH == 0) * 4);
     Chain32<MT, KSH, KSN> ch(red);
     ch.template prefetch_n<0>(a.cf[0]);
     // ---- the actor forward pass of this tile was made alongside the critic phase ----
@@ -804,7 +851,7 @@ __global__ __launch_bounds__(64 * NW32) void actor_infer32_kernel(const ActorInf
     float* xin = (float*)carve(M * a.ldx * 4);
     float* bufA = (float*)carve(M * a.ldh * 4);
     float* bufB = (float*)carve(M * a.ldh * 4);
-    float* red = (float*)carve((NW32 - 1) * MT * 256 * 4);
+    float* red = (float*)carve(red_floats32(MT, KSH == 0) * 4);
     Chain32<MT, KSH, KSN> ch(red);
     ch.template prefetch_n<0>(a.l[0]);
     const int ldh = a.ldh, ldx = a.ldx, E = a.E, ld_act = a.ld_act;
@@ -837,15 +884,15 @@ __global__ __launch_bounds__(64 * NW32) void actor_infer32_kernel(const ActorInf
 }
 
 // ---- host launchers -----------------------------------------------------------------------------
-static int lds_bytes_critic32(const PhaseDims& d, int M, int mt) {
+static int lds_bytes_critic32(const PhaseDims& d, int M, int mt, bool wide = false) {
     auto al = [](int b) { return (b + 15) & ~15; };
     return 2 * al(M * d.ldx * 4) + 4 * al(M * d.ldh * 4) + al(M * d.ldd * 4) + 2 * al(M * d.nop * 4) +
-           al(NW32 * ((d.NO + 63) & ~63) * 4) + al(4 * M * 4) + (critic_red_aliased(d) ? 0 : al((NW32 - 1) * mt * 256 * 4));
+           al(NW32 * ((d.NO + 63) & ~63) * 4) + al(4 * M * 4) + (critic_red_aliased(d, wide) ? 0 : al(red_floats32(mt, wide) * 4));
 }
-static int lds_bytes_actor32(const PhaseDims& d, int M, int mt) {
+static int lds_bytes_actor32(const PhaseDims& d, int M, int mt, bool wide = false) {
     auto al = [](int b) { return (b + 15) & ~15; };
     return al(M * d.ldx * 4) + 4 * al(M * d.ldh * 4) + al(M * d.ldd * 4) + al(M * d.lda_ * 4) + al(M * d.nop * 4) +
-           al((NW32 - 1) * mt * 256 * 4);
+           al(red_floats32(mt, wide) * 4);
 }
 
 #define D4PG_PHASE32_LAUNCHER(NAME, KERNEL, ARGS)                                                         \
@@ -866,6 +913,22 @@ D4PG_PHASE32_LAUNCHER(launch_critic32_ksh, critic_phase32_kernel, CriticPhaseArg
 D4PG_PHASE32_LAUNCHER(launch_infer32_ksh, actor_infer32_kernel, ActorInferArgs32)
 D4PG_PHASE32_LAUNCHER(launch_actor32_ksh, actor_phase32_kernel, ActorPhaseArgs32)
 
+// the 16x16x4 path (KSH = 0): tiles of 8 or 16 rows, every width at run time
+#define D4PG_PHASE32W_LAUNCHER(NAME, KERNEL, ARGS)                                                        \
+    int NAME(const ARGS* a, int mt, int grid, int lds, hipStream_t stream) {                               \
+        if (mt == 2) return launch_phase(KERNEL<2, 0, 0>, *a, grid, NW32, lds, stream);                    \
+        return launch_phase(KERNEL<4, 0, 0>, *a, grid, NW32, lds, stream);                                 \
+    }
+#if D4PG_KSH_PART == 0 || D4PG_KSH_PART == 99
+D4PG_PHASE32W_LAUNCHER(launch_critic32_wide, critic_phase32_kernel, CriticPhaseArgs32)
+D4PG_PHASE32W_LAUNCHER(launch_actor32_wide, actor_phase32_kernel, ActorPhaseArgs32)
+D4PG_PHASE32W_LAUNCHER(launch_infer32_wide, actor_infer32_kernel, ActorInferArgs32)
+#else
+int launch_critic32_wide(const CriticPhaseArgs32*, int, int, int, hipStream_t);
+int launch_actor32_wide(const ActorPhaseArgs32*, int, int, int, hipStream_t);
+int launch_infer32_wide(const ActorInferArgs32*, int, int, int, hipStream_t);
+#endif
+
 #define D4PG_PHASE32_INSTANCES(PREFIX, KSHV)                                                                   \
     PREFIX template int launch_critic32_ksh<KSHV>(const CriticPhaseArgs32*, int, int, int, int, hipStream_t);  \
     PREFIX template int launch_actor32_ksh<KSHV>(const ActorPhaseArgs32*, int, int, int, int, hipStream_t);   \
@@ -874,7 +937,7 @@ D4PG_PHASE32_LAUNCHER(launch_actor32_ksh, actor_phase32_kernel, ActorPhaseArgs32
 D4PG_PHASE32_INSTANCES(extern, 13)
 D4PG_PHASE32_INSTANCES(extern, 4)
 D4PG_PHASE32_INSTANCES(extern, 8)
-#elif D4PG_KSH_PART != 99        // the unit of one width
+#elif D4PG_KSH_PART != 99 && D4PG_KSH_PART != 0        // the unit of one width
 D4PG_PHASE32_INSTANCES(, D4PG_KSH_PART)
 #endif
 
@@ -1017,6 +1080,98 @@ D4PG_API int d4pg_actor_infer32(const ActorInferArgs32* a, int mt, hipStream_t s
 #endif
 }
 
+// ---- the 16x16x4 path: any widths at run time (csrc/mlp16_dev.h) ---------------------------------
+// `ld` = floats readable per row of the LDS tile the layer multiplies
+static int check_layer16(const LayerW32& L, int ld) {
+    if (L.W == nullptr || L.bias == nullptr || (((uintptr_t)L.W) & 15)) return -6;
+    if (L.ntiles < 1 || L.ks < 1 || L.ksplit < 1 || L.nch < 1 || L.N < 1 || L.N > 16 * L.ntiles) return -6;
+    if (L.ksplit > 1 && L.ntiles * L.ksplit > NW32) return -7;                       // one K-slice of one tile per wave
+    if (L.nch * L.ksplit < L.ks || (L.ksplit - 1) * L.nch >= L.ks) return -7;        // the slices cover K, none is empty
+    if (L.ks * 16 > ld) return -7;
+    if ((long long)L.ntiles * L.ks * GROUP16_BYTES >= (1ll << 31)) return -7;
+    return 0;
+}
+static int check_dims16(const PhaseDims& d, int M) {
+    if (int rc = check_dims32(d, M)) return rc;
+    if (d.ldh < ((d.H + 15) & ~15) || d.ldd < ((d.NO + 15) & ~15) || d.lda_ < ((d.A + 15) & ~15) ||
+        d.ldx < ((d.S + d.A + 15) & ~15))
+        return -3;
+    return 0;
+}
+
+D4PG_API int d4pg_critic_phase32w(const CriticPhaseArgs32* a, int mt, hipStream_t stream) {
+    const PhaseDims& d = a->d;
+    if (mt != 2 && mt != 4) return -9;
+    const int M = 4 * mt;
+    if (int rc = check_dims16(d, M)) return rc;
+    const LayerW32* nets[4] = {a->ta, a->tc, a->cf, a->fwd.af};
+    for (int i = 0; i < 4; ++i) {
+        if (int rc = check_layer16(nets[i][0], d.ldx)) return rc;
+        if (int rc = check_layer16(nets[i][1], d.ldh)) return rc;
+        if (int rc = check_layer16(nets[i][2], d.ldh)) return rc;
+    }
+    if (int rc = check_layer16(a->cb3, d.ldd)) return rc;
+    if (int rc = check_layer16(a->cb2, d.ldh)) return rc;
+    if (a->fwd.g_xin == nullptr || a->fwd.g_h1 == nullptr || a->fwd.g_h2 == nullptr || a->fwd.sT == nullptr ||
+        a->fwd.h1T == nullptr || a->fwd.h2T == nullptr)
+        return -14;
+    if (int prc = check_packed(a->pk, d)) return prc;
+    if (a->ahead.mode != 0 && (a->ahead.h1 == nullptr || a->ahead.h2 == nullptr || a->ahead.lg == nullptr)) return -15;
+    const int grid = 2 * (d.B / M) + n_warmers32(d, M);
+    return launch_critic32_wide(a, mt, grid, lds_bytes_critic32(d, M, mt, true), stream);
+}
+
+D4PG_API int d4pg_actor_phase32w(const ActorPhaseArgs32* a, int mt, hipStream_t stream) {
+    const PhaseDims& d = a->d;
+    if (mt != 2 && mt != 4) return -9;
+    const int M = 4 * mt;
+    if (int rc = check_dims16(d, M)) return rc;
+    if (int rc = check_layer16(a->cf[0], d.ldx)) return rc;
+    if (int rc = check_layer16(a->cf[1], d.ldh)) return rc;
+    if (int rc = check_layer16(a->cf[2], d.ldh)) return rc;
+    if (int rc = check_layer16(a->cb3, d.ldd)) return rc;
+    if (int rc = check_layer16(a->cb2, d.ldh)) return rc;
+    if (int rc = check_layer16(a->cb1, d.ldh)) return rc;
+    if (int rc = check_layer16(a->ab3, d.lda_)) return rc;
+    if (int rc = check_layer16(a->ab2, d.ldh)) return rc;
+    if (a->g_xin == nullptr || a->g_h1 == nullptr || a->g_h2 == nullptr) return -14;
+    if (a->tree.n < 0 || (a->tree.n > 0 && (a->tree.idx == nullptr || a->tree.prio == nullptr || a->tree.t.L < 0 ||
+                                            a->tree.t.L > MAXL || a->tree.parts > 64 ||
+                                            (a->tree.parts > 1 && (a->tree.t.L < 2 || a->tree.ticket == nullptr)))))
+        return -11;
+    if (a->ahead.mode != 0) {
+        if (a->ahead.mode < 0 || a->ahead.mode > 3 || (a->ahead.mode != 3 && !a->pk.enabled)) return -15;
+        if (a->ahead.h1 == nullptr || a->ahead.h2 == nullptr || a->ahead.lg == nullptr || a->c_saT == nullptr ||
+            a->c_h1T == nullptr || a->c_h2T == nullptr)
+            return -15;
+        if (a->ahead.mode == 3) {
+            if (a->smp == nullptr || a->pk.st == nullptr || a->pk.enabled || a->tree.n > 0) return -16;
+        } else if (int prc = check_packed(a->pk, d)) {
+            return prc;
+        }
+    }
+    const int n_ahead = a->ahead.mode != 0 ? d.B / M : 0;
+    const int grid = d.B / M + (a->tree.n > 0 ? (a->tree.parts > 1 ? a->tree.parts : 1) : 0) + n_ahead + n_warmers32(d, M);
+    return launch_actor32_wide(a, mt, grid, lds_bytes_actor32(d, M, mt, true), stream);
+}
+
+D4PG_API int d4pg_actor_infer32w(const ActorInferArgs32* a, int mt, hipStream_t stream) {
+    if (mt != 2 && mt != 4) return -9;
+    if (a->E < 1 || a->S < 1 || a->A < 1 || a->A > 64 || a->obs == nullptr || a->act == nullptr) return -1;
+    if ((a->ldx & 3) || (a->ldh & 3) || a->ldx < a->S || a->ld_obs < a->S || a->ld_act < a->A) return -3;
+    const int M = 4 * mt;
+    if (int rc = check_layer16(a->l[0], a->ldx)) return rc;
+    if (int rc = check_layer16(a->l[1], a->ldh)) return rc;
+    if (int rc = check_layer16(a->l[2], a->ldh)) return rc;
+    auto al = [](int b) { return (b + 15) & ~15; };
+    const int lds = al(M * a->ldx * 4) + 2 * al(M * a->ldh * 4) + al(red_floats32(mt, true) * 4);
+    return launch_infer32_wide(a, mt, (a->E + M - 1) / M, lds, stream);
+}
+
+D4PG_API int d4pg_phase32w_lds_bytes(const PhaseDims* d, int mt, int actor) {
+    return actor ? lds_bytes_actor32(*d, 4 * mt, mt, true) : lds_bytes_critic32(*d, 4 * mt, mt, true);
+}
+
 D4PG_API int d4pg_phase32_lds_bytes(const PhaseDims* d, int mt, int actor) {
     return actor ? lds_bytes_actor32(*d, 4 * mt, mt) : lds_bytes_critic32(*d, 4 * mt, mt);
 }
@@ -1046,7 +1201,7 @@ struct WgradGroup32 {
     WgradDesc32 p[3];
     int count, total_tiles;
     int Bp;
-    int pad_;
+    int wide;                  // packed copies in the order of csrc/mlp16_dev.h (packed16_off, sf_ks / sb_ks = 16-wide k-groups)
     WgradAdam opt;
     const SampleArgs* smp;     // prioritised replay: the next batch is drawn by extra workgroups (csrc/fused.hip)
     int smp_rows;
@@ -1156,12 +1311,12 @@ __global__ __launch_bounds__(64 * NWV) void wgrad32_kernel(const WgradGroup32 g)
                 float tv;
                 const float pv = adam_apply(o, d.w_off + (long long)cm * d.ldc + cn, ast[i], gv, step_size, inv_sqrt_bc2, tv);
                 if (d.sf_off >= 0) {
-                    const long long so = d.sf_off + packed32_off(cm, cn, d.sf_ks);
+                    const long long so = d.sf_off + (g.wide ? packed16_off(cm, cn, d.sf_ks) : packed32_off(cm, cn, d.sf_ks));
                     ps[so] = pv;
                     ts[so] = tv;
                 }
                 if (d.sb_off >= 0 && cn >= d.sb_c0 && cn < d.sb_c1)
-                    ps[d.sb_off + packed32_off(cn - d.sb_c0, cm, d.sb_ks)] = pv;
+                    ps[d.sb_off + (g.wide ? packed16_off(cn - d.sb_c0, cm, d.sb_ks) : packed32_off(cn - d.sb_c0, cm, d.sb_ks))] = pv;
             }
         }
     }
@@ -1214,7 +1369,8 @@ D4PG_API int d4pg_wgrad32(WgradGroup32* g, hipStream_t stream) {
     }
     g->total_tiles = base;
     int nwv = g->Bp >= 128 ? 16 : (g->Bp >= 64 ? 8 : 4);     // one group of 8 batch rows per wave up to 16 waves
-    if (const char* e = getenv("D4PG_WGRAD_WAVES")) nwv = atoi(e);
+    static const int forced_waves = [] { const char* e = getenv("D4PG_WGRAD_WAVES"); return e ? atoi(e) : 0; }();      // (A/B runs)
+    if (forced_waves) nwv = forced_waves;
     if (nwv == 16) return launch_wgrad32(wgrad32_kernel<16>, 16, base, *g, stream);
     if (nwv == 8) return launch_wgrad32(wgrad32_kernel<8>, 8, base, *g, stream);
     return launch_wgrad32(wgrad32_kernel<4>, 4, base, *g, stream);

@@ -13,6 +13,7 @@
 //                       update is driven without the replay-sampling kernel.
 #include "common.h"
 #include "mlp32_dev.h"
+#include "mlp16_dev.h"
 
 // bf16 "shadow" copies of the weight matrices for the fused bf16 pipeline (csrc/fused.hip).
 // The optimiser kernel refreshes them in the same pass that updates the fp32 masters:
@@ -70,8 +71,17 @@ __device__ __forceinline__ void write_shadows(const ShadowArgs& sh, long long e,
         for (int k = 0; k < 4; ++k) {
             const int i = i0 + k;
             if (i >= m.in_dim) continue;
-            if (sh.f32) {
+            if (sh.f32) {      // 1: packed32_off (csrc/mlp32_dev.h), 2: packed16_off (csrc/mlp16_dev.h); f_ld / b_ld = padded K
                 float* ps = (float*)sh.p_shadow;
+                if (sh.f32 == 2) {
+                    if (m.f_off >= 0) {
+                        const long long so = m.f_off + packed16_off(o, i, m.f_ld >> 4);
+                        ps[so] = p[k];
+                        if (sh.t_shadow != nullptr && t != nullptr) ((float*)sh.t_shadow)[so] = (*t)[k];
+                    }
+                    if (m.b_off >= 0 && i >= m.b_c0 && i < m.b_c1) ps[m.b_off + packed16_off(i - m.b_c0, o, m.b_ld >> 4)] = p[k];
+                    continue;
+                }
                 if (m.f_off >= 0) {
                     const long long so = m.f_off + packed32_off(o, i, m.f_ld >> 5);
                     ps[so] = p[k];

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(64) void planar_step_kernel(const PlanarEnvArgs a) 
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned long long ctr = *a.counter;
     if (e >= a.E) return;
-    const PlanarParams* __restrict__ P = a.P;
+    const PlanarParams* P = a.P;
     float* st = a.state + (size_t)e * STRIDE;
     float q[n], qd[n];
 #pragma unroll

@@ -13,6 +13,12 @@
 // the Jacobians cost nothing.  The NUMBERS (masses, lengths, gains...) come from the Python model at run time
 // (PlanarParams), so the three implementations cannot drift apart.
 #pragma once
+// Pointer parameters of the simulator functions are not restrict-qualified: with `__restrict__` on the parameter
+// block hipcc 7.2 miscompiles the 3-D twin of this code at -O2 / -O3 (csrc/ant_sim.h has the evidence); nothing
+// here ever writes through an alias, so the qualifier bought nothing but that exposure.
+#ifndef PSIM_RESTRICT
+#define PSIM_RESTRICT
+#endif
 #include <math.h>
 #if defined(__HIPCC__)
 #define PSIM_RCP(x) __frcp_rn(x)
@@ -83,7 +89,7 @@ struct TerrainWindow {
     int j0;
     bool on;
 };
-PSIM_FN void load_window(const float* __restrict__ terrain, int ts, float x, TerrainWindow& w) {
+PSIM_FN void load_window(const float* PSIM_RESTRICT terrain, int ts, float x, TerrainWindow& w) {
     w.on = terrain != nullptr;
     int j0 = (int)floorf((x - 2.5f) * INV_STEP);
     w.j0 = j0 < 0 ? 0 : (j0 > TERRAIN_LENGTH - WINDOW ? TERRAIN_LENGTH - WINDOW : j0);
@@ -116,7 +122,7 @@ constexpr bool above(int link, int k) { return (ANCESTRY<T> >> (8 * link + k)) &
 
 // q'' for joint torques tau; sets the bits of `contact` for the contact points that touch
 template <class T>
-PSIM_FN void accelerations(const PlanarParams* __restrict__ P, const float (&q)[T::L + 2], const float (&qd)[T::L + 2],
+PSIM_FN void accelerations(const PlanarParams* PSIM_RESTRICT P, const float (&q)[T::L + 2], const float (&qd)[T::L + 2],
                                               const float (&tau)[T::L], float (&qdd)[T::L + 2], unsigned& contact,
                                               const biped::TerrainWindow& terrain) {
     constexpr int L = T::L, n = L + 2;
@@ -255,8 +261,8 @@ PSIM_FN void accelerations(const PlanarParams* __restrict__ P, const float (&q)[
 }
 
 template <class T>
-PSIM_FN void observe(const float (&q)[T::L + 2], const float (&qd)[T::L + 2], float c0, float c1, float* __restrict__ o,
-                     const float* __restrict__ terrain, int ts) {
+PSIM_FN void observe(const float (&q)[T::L + 2], const float (&qd)[T::L + 2], float c0, float c1, float* PSIM_RESTRICT o,
+                     const float* PSIM_RESTRICT terrain, int ts) {
     constexpr int n = T::L + 2;
     constexpr float LIDAR_SIN[10] = LIDAR_SIN_TABLE, LIDAR_COS[10] = LIDAR_COS_TABLE;
     if (T::TASK == 0) {
@@ -317,8 +323,8 @@ PSIM_FN void observe(const float (&q)[T::L + 2], const float (&qd)[T::L + 2], fl
 // One environment step without the episode bookkeeping: sub-steps, then reward and termination of the task.
 // `raw` points at the T::A action components of this environment.
 template <class T>
-PSIM_FN void advance(const PlanarParams* __restrict__ P, float (&q)[T::L + 2], float (&qd)[T::L + 2], const float* __restrict__ raw,
-                     float& c0, float& c1, float& prev, float& rew, bool& term, const float* __restrict__ terrain,
+PSIM_FN void advance(const PlanarParams* PSIM_RESTRICT P, float (&q)[T::L + 2], float (&qd)[T::L + 2], const float* PSIM_RESTRICT raw,
+                     float& c0, float& c1, float& prev, float& rew, bool& term, const float* PSIM_RESTRICT terrain,
                      int terrain_stride) {
     constexpr int L = T::L, n = L + 2;
     float act[T::A], raw2 = 0.f, abs_sum = 0.f;

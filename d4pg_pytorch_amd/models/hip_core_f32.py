@@ -31,7 +31,10 @@ from .hip_core_bf16 import LDS_LIMIT, HipCoreBf16, ShapeLimit
 from .nets import LayerSlot, Packed32, Shadow32Layout, Shadow32Slot, pad16, pad32, refresh_shadows32
 
 LDS_PAD32 = 4
-SUPPORTED_HIDDEN_CHUNKS = (4, 8, 13)      # phase kernels exist for hidden widths of 97..128, 225..256, 385..416
+SUPPORTED_HIDDEN_CHUNKS = (4, 8, 13)      # 4-row-tile phase kernels exist for hidden widths of 97..128, 225..256, 385..416
+#: batch size from which the 16x16x4 kernels (``csrc/mlp16_dev.h``, tiles of 16 rows) replace the 4x4x1 ones for the
+#: compiled widths (other widths always take them)
+WIDE_FROM_BATCH = 2048
 
 
 class HipCoreF32(HipCoreBf16):
@@ -40,6 +43,7 @@ class HipCoreF32(HipCoreBf16):
     _fn_critic, _fn_actor = "d4pg_critic_phase32", "d4pg_actor_phase32"
     rows_per_tile_unit = 4
     supports_per_ahead = True
+    wide = False
 
     def __init__(self, cfg: Dict, device="cuda", seed: Optional[int] = None):
         HipCore.__init__(self, cfg, device, seed)
@@ -47,14 +51,27 @@ class HipCoreF32(HipCoreBf16):
         B, S, A, Hd, NO = self.B, self.S, self.A, self.Hd, self.NO
         waves = H.lib().d4pg_phase32_waves()
         ksh = pad32(Hd) // 32
-        if ksh not in SUPPORTED_HIDDEN_CHUNKS or (Hd + 63) // 64 > waves:
-            raise ShapeLimit(f"dense_size={Hd}: the fused fp32 pipeline is built for hidden widths "
+        narrow_ok = ksh in SUPPORTED_HIDDEN_CHUNKS and (Hd + 63) // 64 <= waves and pad32(S + A) <= 128
+        if NO > 64 or A > 64:
+            raise ShapeLimit("the fused fp32 pipeline needs <= 64 atoms and <= 64 actions")
+        # Two sets of phase kernels.  4x4x1 MFMA on tiles of 4 / 8 / 16 rows, one compiled instance per hidden width
+        # class: the fast one while an update is a latency-bound chain.  16x16x4 MFMA on tiles of 8 / 16 rows, every
+        # width at run time: for batches that fill the chip (a 4x4x1 kernel with 8- or 16-row tiles issues as many
+        # other instructions as MFMAs and keeps the matrix pipe 44 % busy) and for every other hidden width.
+        want = str(cfg.get("phase_tile_rows", "auto"))
+        mfma = str(cfg.get("phase_mfma", "auto"))          # auto | 4x4 | 16x16
+        if mfma == "auto":
+            self.wide = (not narrow_ok) or (B >= WIDE_FROM_BATCH and B % 16 == 0 and want in ("auto", "16"))
+        else:
+            self.wide = mfma == "16x16"
+        if not self.wide and not narrow_ok:
+            raise ShapeLimit(f"dense_size={Hd}: the 4x4x1 phase kernels are built for hidden widths "
                              f"{[f'{32 * k - 31}..{32 * k}' for k in SUPPORTED_HIDDEN_CHUNKS]}")
-        if NO > 64 or A > 64 or pad32(S + A) > 128 or pad32(NO) > 128:
-            raise ShapeLimit("the fused fp32 pipeline needs <= 64 atoms, <= 64 actions and state + action <= 128")
-        if B % 4:
-            raise ShapeLimit("the fused fp32 pipeline needs batch_size to be a multiple of 4")
-        self.sl = Shadow32Layout.build(lay, waves)
+        if B % (8 if self.wide else 4):
+            raise ShapeLimit(f"the fused fp32 pipeline needs batch_size to be a multiple of {8 if self.wide else 4}")
+        if self.wide:
+            self._fn_critic, self._fn_actor = "d4pg_critic_phase32w", "d4pg_actor_phase32w"
+        self.sl = Shadow32Layout.build(lay, waves, wide=self.wide)
         self.shadow_online = torch.zeros(self.sl.numel, dtype=torch.float32, device=dev)
         self.shadow_target = torch.zeros(self.sl.numel, dtype=torch.float32, device=dev)
         self.Bp = pad32(B)
@@ -81,15 +98,21 @@ class HipCoreF32(HipCoreBf16):
         # tiles while their workgroups (critic + actor forward) fit the 256 CUs, taller tiles beyond.  Measured
         # (us per update, 4 / 8 / 16 rows): batch 512: 86 / 96 / -, 1024: 117 / 105 / -, 2048: 205 / 147 / 186,
         # 4096 (Ant): 451 / 329 / 311  (bench/exp/ab_tile32.sh).
-        want = str(cfg.get("phase_tile_rows", "auto"))
-        if want in ("4", "8", "16"):
+        lds_fn = H.lib().d4pg_phase32w_lds_bytes if self.wide else H.lib().d4pg_phase32_lds_bytes
+
+        def lds_need(mt: int) -> int:
+            return max(lds_fn(self.dims, mt, 0), lds_fn(self.dims, mt, 1))
+        if self.wide:
+            # 16 rows use every row of the MFMA; 8 rows (half of each instruction spent on copies) where 16 do not
+            # divide the batch or four 16-row hidden tiles do not fit the LDS (widths beyond ~470)
+            self.mt = 2 if (want == "8" or B % 16 or lds_need(4) > LDS_LIMIT) else 4
+        elif want in ("4", "8", "16"):
             self.mt = int(want) // 4
         else:
             self.mt = 1 if B // 4 <= 128 else (2 if B // 8 <= 256 else 4)
-        while self.mt > 1 and B % (4 * self.mt):
+        while not self.wide and self.mt > 1 and B % (4 * self.mt):
             self.mt //= 2
-        need = max(H.lib().d4pg_phase32_lds_bytes(self.dims, self.mt, 0),
-                   H.lib().d4pg_phase32_lds_bytes(self.dims, self.mt, 1))
+        need = lds_need(self.mt)
         if need > LDS_LIMIT:
             raise ShapeLimit(f"dense_size={Hd} needs {need} bytes of LDS per workgroup (> {LDS_LIMIT})")
         self.refresh_shadows()
@@ -104,6 +127,13 @@ class HipCoreF32(HipCoreBf16):
     def _phase_dims(self) -> H.PhaseDims:
         d = super()._phase_dims()
         sl = self.sl
+        if self.wide:      # K padded to groups of 16; + 4 floats: consecutive rows start 4 banks apart (mod 16 rows)
+            d.ldx = pad16(self.S + self.A) + LDS_PAD32
+            d.ldh = pad16(self.Hd) + LDS_PAD32
+            d.ldd = pad16(self.NO) + LDS_PAD32
+            d.lda_ = pad16(self.A) + LDS_PAD32
+            d.nop = pad16(self.NO)
+            return d
         hidden_ks = max(sl.actor[1].f.ks, sl.actor[2].f.ks, sl.critic[2].f.ks, sl.critic[0].b.ks)
         d.ldx = pad32(self.S + self.A) + LDS_PAD32
         d.ldh = 32 * hidden_ks + LDS_PAD32        # K-sliced output layers pad K up to a multiple of the slices
@@ -136,7 +166,7 @@ class HipCoreF32(HipCoreBf16):
             d.sb_off = sh.b.off if sh.b is not None else -1
             d.sb_ks = sh.b.ks if sh.b is not None else 0
             d.sb_c0, d.sb_c1 = sh.b_c0, sh.b_c1
-        g.count, g.Bp = len(triples), self.Bp
+        g.count, g.Bp, g.wide = len(triples), self.Bp, int(self.wide)
         if opt is not None:
             lr, finish = opt
             o = g.opt
@@ -167,9 +197,10 @@ class HipCoreF32(HipCoreBf16):
             m.f_off = sh.f.off
             m.b_off = sh.b.off if sh.b is not None else -1
             m.out_dim, m.in_dim, m.ld = s.out_dim, s.in_dim, s.ld
-            m.f_ld = sh.f.ks * 32
-            m.b_ld = sh.b.ks * 32 if sh.b is not None else 0
+            unit = 16 if self.wide else 32
+            m.f_ld = sh.f.ks * unit
+            m.b_ld = sh.b.ks * unit if sh.b is not None else 0
             m.b_c0, m.b_c1 = sh.b_c0, sh.b_c1
         sa.count = 3
-        sa.f32 = 1
+        sa.f32 = 2 if self.wide else 1
         return sa

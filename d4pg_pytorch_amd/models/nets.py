@@ -340,10 +340,25 @@ class Packed32:
     ks: int
     ksplit: int
     nch: int
+    #: fragment order of ``v_mfma_f32_16x16x4_f32`` (``packed16_off`` in ``csrc/mlp16_dev.h``):
+    #: ``[n/16][k/16][(k%16)/4][n%16][k%4]``, ``ntiles`` column tiles of 16, ``ks`` groups of 16 k
+    wide: bool = False
 
     @property
     def numel(self) -> int:
-        return self.ntiles * self.ks * 2048
+        return self.ntiles * self.ks * (256 if self.wide else 2048)
+
+    @staticmethod
+    def geometry_wide(N: int, K: int, waves: int):
+        """Tiles of 16 columns, groups of 16 k.  A layer with at most ``waves / 2`` column tiles is dealt to the
+        waves in K-slices (one slice of one tile per wave, no slice empty)."""
+        ntiles, ks = (N + 15) // 16, (K + 15) // 16
+        want = 1
+        while ntiles * want * 2 <= waves:
+            want *= 2
+        nch = (ks + want - 1) // want
+        ksplit = (ks + nch - 1) // nch
+        return ntiles, ks, ksplit, nch
 
     @staticmethod
     def geometry(N: int, K: int, split: bool, waves: int):
@@ -374,13 +389,16 @@ class Shadow32Layout:
     numel: int
 
     @staticmethod
-    def build(lay: "LearnerLayout", waves: int) -> "Shadow32Layout":
+    def build(lay: "LearnerLayout", waves: int, wide: bool = False) -> "Shadow32Layout":
         off = 0
 
         def packed(N, K, split):
             nonlocal off
-            nt, ks, ksplit, nch = Packed32.geometry(N, K, split, waves)
-            p = Packed32(off, N, K, nt, ks, ksplit, nch)
+            if wide:
+                nt, ks, ksplit, nch = Packed32.geometry_wide(N, K, waves)
+            else:
+                nt, ks, ksplit, nch = Packed32.geometry(N, K, split, waves)
+            p = Packed32(off, N, K, nt, ks, ksplit, nch, wide)
             off += p.numel
             return p
 
@@ -402,6 +420,11 @@ class Shadow32Layout:
 
 def pack32(m: torch.Tensor, p: Packed32) -> torch.Tensor:
     """``m[N, K]`` -> the flat packed copy described by ``p`` (zero padded)."""
+    if p.wide:
+        full = torch.zeros(p.ntiles * 16, p.ks * 16, dtype=torch.float32, device=m.device)
+        full[: m.shape[0], : m.shape[1]] = m
+        # [tile][c][group][q][j] -> [tile][group][q][c][j]
+        return full.reshape(p.ntiles, 16, p.ks, 4, 4).permute(0, 2, 3, 1, 4).reshape(-1)
     full = torch.zeros(p.ntiles * 64, p.ks * 32, dtype=torch.float32, device=m.device)
     full[: m.shape[0], : m.shape[1]] = m
     return full.reshape(p.ntiles, 64, p.ks * 8, 4).permute(0, 2, 1, 3).reshape(-1)
@@ -409,6 +432,8 @@ def pack32(m: torch.Tensor, p: Packed32) -> torch.Tensor:
 
 def unpack32(flat: torch.Tensor, p: Packed32) -> torch.Tensor:
     """Inverse of :func:`pack32` (true rows / columns only)."""
+    if p.wide:
+        return flat.reshape(p.ntiles, p.ks, 4, 16, 4).permute(0, 3, 1, 2, 4).reshape(p.ntiles * 16, p.ks * 16)[: p.N, : p.K]
     return flat.reshape(p.ntiles, p.ks * 8, 64, 4).permute(0, 2, 1, 3).reshape(p.ntiles * 64, p.ks * 32)[: p.N, : p.K]
 
 

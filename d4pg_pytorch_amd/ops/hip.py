@@ -258,7 +258,7 @@ class WgradDesc32(C.Structure):
 
 class WgradGroup32(C.Structure):
     _fields_ = [("p", WgradDesc32 * 3), ("count", C.c_int), ("total_tiles", C.c_int), ("Bp", C.c_int),
-                ("pad_", C.c_int), ("opt", WgradAdam), ("smp", vp), ("smp_rows", C.c_int), ("tree_parts", C.c_int),
+                ("wide", C.c_int), ("opt", WgradAdam), ("smp", vp), ("smp_rows", C.c_int), ("tree_parts", C.c_int),
                 ("tree", vp)]
 
 
@@ -443,6 +443,10 @@ def lib() -> C.CDLL:
             ("d4pg_critic_phase32", [C.POINTER(CriticPhaseArgs32), C.c_int, vp]),
             ("d4pg_actor_phase32", [C.POINTER(ActorPhaseArgs32), C.c_int, vp]),
             ("d4pg_phase32_lds_bytes", [C.POINTER(PhaseDims), C.c_int, C.c_int]),
+            ("d4pg_critic_phase32w", [C.POINTER(CriticPhaseArgs32), C.c_int, vp]),
+            ("d4pg_actor_phase32w", [C.POINTER(ActorPhaseArgs32), C.c_int, vp]),
+            ("d4pg_actor_infer32w", [C.POINTER(ActorInferArgs32), C.c_int, vp]),
+            ("d4pg_phase32w_lds_bytes", [C.POINTER(PhaseDims), C.c_int, C.c_int]),
             ("d4pg_wgrad32", [C.POINTER(WgradGroup32), vp]),
             ("d4pg_actor_infer32", [C.POINTER(ActorInferArgs32), C.c_int, vp]),
             ("d4pg_pack_actor32", [C.POINTER(PackActorArgs32), vp]),

@@ -33,8 +33,17 @@ CASES = [("d4pg", {}), ("d4pg", {"critic_loss": "ce", "dense_size": 128}), ("d3p
          ("d4pg", {"env": "Ant-v2", "batch_size": 128, "use_per_sample_gamma": False}),       # 4 input chunks
          ("ddpg", {"env": "Pendulum-v0", "dense_size": 100, "batch_size": 64}),
          ("d4pg", {"env": "Walker2d-v2", "batch_size": 1024, "dense_size": 256}),             # 8-row tiles
-         ("d4pg", {"env": "BipedalWalker-v2", "batch_size": 2048, "phase_tile_rows": "16"}),  # 16-row tiles
-         ("d4pg", {"batch_size": 36, "phase_tile_rows": "4"})]                                # batch not a multiple of 32
+         ("d4pg", {"env": "BipedalWalker-v2", "batch_size": 2048, "phase_tile_rows": "16", "phase_mfma": "4x4"}),  # 16-row tiles
+         ("d4pg", {"batch_size": 36, "phase_tile_rows": "4"}),                                # batch not a multiple of 32
+         # the 16x16x4 kernels (csrc/mlp16_dev.h): large batches, and every hidden width the 4x4x1 kernels are not built for
+         ("d4pg", {"env": "BipedalWalker-v2", "batch_size": 2048}),
+         ("d4pg", {"env": "Ant-v2", "batch_size": 512, "phase_mfma": "16x16"}),               # 8 k-groups of input
+         ("d4pg", {"dense_size": 64}),                                                        # hidden layers in K-slices
+         ("d4pg", {"dense_size": 300}),
+         ("d3pg", {"dense_size": 300, "env": "Walker2d-v2"}),
+         ("d4pg", {"dense_size": 512}),                                                       # 32 column tiles: 4 per wave
+         ("d4pg", {"dense_size": 1024, "batch_size": 64}),                                    # two passes, 8-row tiles
+         ("d4pg", {"dense_size": 200, "batch_size": 136})]                                    # 8-row tiles (136 = 8 * 17)
 
 
 def test_default_dtype_is_the_fused_fp32_pipeline():
@@ -47,8 +56,10 @@ def test_default_dtype_is_the_fused_fp32_pipeline():
     assert default_config(env="Pendulum-v0")["compute_dtype"] == "auto"
     assert isinstance(build_core(_cfg("d4pg"), "cuda"), HipCoreF32)
     assert isinstance(build_core(_cfg("d4pg", compute_dtype="fp32"), "cuda"), HipCoreF32)
-    odd = build_core(_cfg("d4pg", dense_size=72), "cuda")
-    assert type(odd) is HipCore
+    odd = build_core(_cfg("d4pg", dense_size=72), "cuda")           # any hidden width: the 16x16x4 kernels
+    assert isinstance(odd, HipCoreF32) and odd.wide
+    assert not build_core(_cfg("d4pg"), "cuda").wide and build_core(_cfg("d4pg", batch_size=4096), "cuda").wide
+    assert type(build_core(_cfg("d4pg", num_atoms=101), "cuda")) is HipCore      # more atoms than a wavefront has lanes
     assert type(build_core(_cfg("d4pg", fused_learner="layers"), "cuda")) is HipCore
     bf = build_core(_cfg("d4pg", compute_dtype="bf16"), "cuda")
     assert type(bf) is HipCoreBf16

@@ -158,7 +158,23 @@ v_min: 0.0
 v_max: 4000.0
 device: cuda
 replay_device: hbm
-compute_dtype: bf16       # throughput stress: bf16 MFMA operands (fp32 masters / Adam / loss); 'fp32' = reference precision, 3x slower here
+compute_dtype: fp32       # the reference's precision (models/d4pg/d4pg.py:73-77); ant_stress_d4pg_bf16.yml is the bf16-operand sibling
+envs_per_agent: 64
+""",
+    "ant_stress_d4pg_bf16.yml": """# bf16-operand sibling of ant_stress_d4pg.yml.  Synthetic Ant-shape stress: obs 111, act 8, batch 4096, 10M-transition HBM replay per rank.
+env: Ant-v2
+synthetic_env: true
+model: d4pg
+num_agents: 3
+num_learners: 8
+batch_size: 4096
+replay_mem_size: 10000000
+replay_memory_prioritized: 1
+v_min: 0.0
+v_max: 4000.0
+device: cuda
+replay_device: hbm
+compute_dtype: bf16       # throughput stress: bf16 MFMA operands (fp32 masters / Adam / loss), lower precision than the reference
 envs_per_agent: 64
 """,
     "ant_stress_d3pg.yml": """# Same stress shape with the scalar (D3PG) critic path.
@@ -172,7 +188,7 @@ replay_mem_size: 10000000
 n_step_returns: 1
 device: cuda
 replay_device: hbm
-compute_dtype: bf16       # throughput stress: bf16 MFMA operands (fp32 masters / Adam / loss); 'fp32' = reference precision, 3x slower here
+compute_dtype: fp32       # the reference's precision; set bf16 for the bf16-operand pipeline (lower precision than the reference)
 envs_per_agent: 64
 """,
     "pendulum_d4pg_device_explorers.yml": """# Pendulum D4PG with the explorers ON the learner's GPU: policy, OU noise, dynamics, n-step rows and replay insert
