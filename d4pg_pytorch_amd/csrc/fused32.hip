@@ -199,19 +199,34 @@ __device__ __forceinline__ void zero_tail(float* buf, int ld, int M, int c0) {
 // `ncols` columns of M batch rows -> LDS tile (remaining columns zero), optionally also into a stash
 __device__ __forceinline__ void load_input(const RowSrc& src, int row0, int M, int ncols, float* dst, int ld_dst,
                                            float* stashT, int Kb) {
-    for (int i = threadIdx.x; i < M * ld_dst; i += blockDim.x) {
-        const int r = i / ld_dst, c = i - r * ld_dst;
-        float v = 0.f;
-        if (c < ncols) {
-            v = row_of(src, row0 + r)[c];
-            if (stashT != nullptr) stashT[stash32_off(c, row0 + r, Kb)] = v;
+    // four elements per thread and round, all four loads issued before the first is used: the rows come from
+    // memory that nothing has touched since they were gathered, and a tile of 16 rows x 132 columns was five
+    // dependent round trips per thread
+    const int n = M * ld_dst;
+    for (int i0 = threadIdx.x; i0 < n; i0 += 4 * blockDim.x) {
+        float v[4];
+        int rr[4], cc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + k * blockDim.x;
+            rr[k] = i / ld_dst;
+            cc[k] = i - rr[k] * ld_dst;
+            v[k] = (i < n && cc[k] < ncols) ? row_of(src, row0 + rr[k])[cc[k]] : 0.f;
         }
-        dst[r * ld_dst + c] = v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + k * blockDim.x;
+            if (i < n) {
+                if (stashT != nullptr && cc[k] < ncols) stashT[stash32_off(cc[k], row0 + rr[k], Kb)] = v[k];
+                dst[i] = v[k];
+            }
+        }
     }
 }
 // L2 warmer: slice `slice` of `nslices` of a packed weight copy is read and discarded (csrc/fused.hip, warm_layer)
-__device__ __forceinline__ void warm_layer(const LayerW32& L, int slice, int nslices, unsigned& acc) {
-    const int chunks = L.ntiles * L.ks * (CHUNK_BYTES / 16);
+// (`wide`: a packed copy in the order of csrc/mlp16_dev.h, 1 KB per column tile and k-group)
+__device__ __forceinline__ void warm_layer(const LayerW32& L, int slice, int nslices, unsigned& acc, bool wide) {
+    const int chunks = L.ntiles * L.ks * ((wide ? GROUP16_BYTES : CHUNK_BYTES) / 16);
     const int per = (chunks + nslices - 1) / nslices;
     const int lo = slice * per, hi = min(chunks, lo + per);
     const u32x4* p = reinterpret_cast<const u32x4*>(L.W);
@@ -459,22 +474,22 @@ __global__ __launch_bounds__(64 * NW32) void critic_phase32_kernel(const CriticP
     if (row0 >= 2 * d.B) {     // beyond both halves: L2 warmers
         const int sl = (blockIdx.x - 2 * (d.B / M)) >> 3, nsl = (gridDim.x - 2 * (d.B / M) + 7) >> 3;
         unsigned acc = 0;
-        warm_layer(a.ta[0], sl, nsl, acc);
-        warm_layer(a.fwd.af[0], sl, nsl, acc);
-        warm_layer(a.ta[1], sl, nsl, acc);
-        warm_layer(a.fwd.af[1], sl, nsl, acc);
-        warm_layer(a.ta[2], sl, nsl, acc);
-        warm_layer(a.fwd.af[2], sl, nsl, acc);
-        warm_layer(a.tc[0], sl, nsl, acc);
-        warm_layer(a.tc[1], sl, nsl, acc);
-        warm_layer(a.tc[2], sl, nsl, acc);
+        warm_layer(a.ta[0], sl, nsl, acc, KSH == 0);
+        warm_layer(a.fwd.af[0], sl, nsl, acc, KSH == 0);
+        warm_layer(a.ta[1], sl, nsl, acc, KSH == 0);
+        warm_layer(a.fwd.af[1], sl, nsl, acc, KSH == 0);
+        warm_layer(a.ta[2], sl, nsl, acc, KSH == 0);
+        warm_layer(a.fwd.af[2], sl, nsl, acc, KSH == 0);
+        warm_layer(a.tc[0], sl, nsl, acc, KSH == 0);
+        warm_layer(a.tc[1], sl, nsl, acc, KSH == 0);
+        warm_layer(a.tc[2], sl, nsl, acc, KSH == 0);
         if (a.ahead.mode == 0) {      // (else the online critic's forward pass was most likely made ahead)
-            warm_layer(a.cf[0], sl, nsl, acc);
-            warm_layer(a.cf[1], sl, nsl, acc);
-            warm_layer(a.cf[2], sl, nsl, acc);
+            warm_layer(a.cf[0], sl, nsl, acc, KSH == 0);
+            warm_layer(a.cf[1], sl, nsl, acc, KSH == 0);
+            warm_layer(a.cf[2], sl, nsl, acc, KSH == 0);
         }
-        warm_layer(a.cb3, sl, nsl, acc);
-        warm_layer(a.cb2, sl, nsl, acc);
+        warm_layer(a.cb3, sl, nsl, acc, KSH == 0);
+        warm_layer(a.cb2, sl, nsl, acc, KSH == 0);
         asm volatile("" ::"v"(acc));
         STAMP_SPAN(0, 25, true);
         return;
@@ -709,14 +724,14 @@ __global__ __launch_bounds__(64 * NW32) void actor_phase32_kernel(const ActorPha
     if ((int)blockIdx.x >= n_work) {                // L2 warmers
         const int sl = (blockIdx.x - n_work) >> 3, nsl = (gridDim.x - n_work + 7) >> 3;
         unsigned acc = 0;
-        warm_layer(a.cf[0], sl, nsl, acc);
-        warm_layer(a.cf[1], sl, nsl, acc);
-        warm_layer(a.cf[2], sl, nsl, acc);
-        warm_layer(a.cb3, sl, nsl, acc);
-        warm_layer(a.cb2, sl, nsl, acc);
-        warm_layer(a.cb1, sl, nsl, acc);
-        warm_layer(a.ab3, sl, nsl, acc);
-        warm_layer(a.ab2, sl, nsl, acc);
+        warm_layer(a.cf[0], sl, nsl, acc, KSH == 0);
+        warm_layer(a.cf[1], sl, nsl, acc, KSH == 0);
+        warm_layer(a.cf[2], sl, nsl, acc, KSH == 0);
+        warm_layer(a.cb3, sl, nsl, acc, KSH == 0);
+        warm_layer(a.cb2, sl, nsl, acc, KSH == 0);
+        warm_layer(a.cb1, sl, nsl, acc, KSH == 0);
+        warm_layer(a.ab3, sl, nsl, acc, KSH == 0);
+        warm_layer(a.ab2, sl, nsl, acc, KSH == 0);
         asm volatile("" ::"v"(acc));
         return;
     }
@@ -1273,15 +1288,49 @@ __global__ __launch_bounds__(64 * NWV) void wgrad32_kernel(const WgradGroup32 g)
     float asum = 0.f;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     const bool want_rowsum = d.rowsum != nullptr && tn == 0;
-#pragma unroll 4
-    for (int gi = g0; gi < g1; ++gi) {
-        f32x4 av = *reinterpret_cast<const f32x4*>(arow + gi * 256);
-        f32x4 bv = *reinterpret_cast<const f32x4*>(brow + gi * 256);
-        av = m_ok ? av : zero;
-        bv = n_ok ? bv : zero;
+    // Software pipeline over the wave's groups of 8 batch rows: WG_DEPTH operand pairs in flight.  (Left to the
+    // compiler the loop is not unrolled and every iteration waits for its own two loads: with the stashes of a
+    // 4096-row batch coming from beyond L2 the matrix pipe was 43 % busy.)  Loads past the wave's range re-read its
+    // last group and are not multiplied.
+    constexpr int WG_DEPTH = 4;
+    f32x4 avq[WG_DEPTH], bvq[WG_DEPTH];
+    if (g1 - g0 <= 2) {      // (workgroup-uniform) small batches: one or two groups per wave, nothing to pipeline
+        for (int gi = g0; gi < g1; ++gi) {
+            f32x4 av = *reinterpret_cast<const f32x4*>(arow + gi * 256);
+            f32x4 bv = *reinterpret_cast<const f32x4*>(brow + gi * 256);
+            av = m_ok ? av : zero;
+            bv = n_ok ? bv : zero;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
-        if (want_rowsum) asum += (av[0] + av[1]) + (av[2] + av[3]);
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
+            if (want_rowsum) asum += (av[0] + av[1]) + (av[2] + av[3]);
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < WG_DEPTH; ++s) {
+            const int gl = min(g0 + s, g1 - 1);
+            avq[s] = *reinterpret_cast<const f32x4*>(arow + gl * 256);
+            bvq[s] = *reinterpret_cast<const f32x4*>(brow + gl * 256);
+        }
+        for (int gi = g0; gi < g1; gi += WG_DEPTH) {
+            const bool more = gi + WG_DEPTH < g1;      // wave-uniform: a next block of WG_DEPTH groups exists
+#pragma unroll
+            for (int s = 0; s < WG_DEPTH; ++s) {
+                f32x4 av = avq[s], bv = bvq[s];
+                if (more) {
+                    const int gl = min(gi + s + WG_DEPTH, g1 - 1);
+                    avq[s] = *reinterpret_cast<const f32x4*>(arow + gl * 256);
+                    bvq[s] = *reinterpret_cast<const f32x4*>(brow + gl * 256);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (gi + s < g1) {      // wave-uniform
+                    av = m_ok ? av : zero;
+                    bv = n_ok ? bv : zero;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
+                    if (want_rowsum) asum += (av[0] + av[1]) + (av[2] + av[3]);
+                }
+            }
+        }
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) red[(wave * 16 + i) * 64 + lane] = acc[i];

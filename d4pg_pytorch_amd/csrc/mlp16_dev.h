@@ -102,34 +102,63 @@ __device__ __forceinline__ void mma_grp16(const f32x4& a, const Grp16& r, f32x4 
             acc[t][T == 1 ? (j4 & 1) : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j4], r.b[t][j4], acc[t][T == 1 ? (j4 & 1) : 0], 0, 0, 0);
 }
 
-// One pass of a wave over its k-groups with T column tiles: three group buffers in rotation (the one being
-// multiplied + two in flight), the A fragment of the next group read from LDS while this one is multiplied.
+// One pass of a wave over its k-groups with T column tiles: RING16 group buffers in rotation (the one being
+// multiplied + RING16 - 1 in flight), the A fragment of the next group read from LDS while this one is multiplied.
 // `t`: the first two groups of the pass (fetch_pass16).
+#ifndef D4PG_RING16
+#define D4PG_RING16 3
+#endif
+constexpr int RING16 = D4PG_RING16;
+static_assert(RING16 >= 3 && RING16 <= 6, "two groups arrive prefetched; the ring holds them and at least one more");
+
+#ifdef D4PG_LDS_ASM      // A fragments by an explicit ds_read_b128 one group ahead of their use (the compiler sinks a plain
+                         // LDS load to just in front of the first MFMA that needs it)
+__device__ __forceinline__ f32x4 lds_frag16(const float* p) {
+    f32x4 v;
+    const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const float*)p;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_frag16_wait() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+#else
+__device__ __forceinline__ f32x4 lds_frag16(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void lds_frag16_wait() {}
+#endif
+
 template <int T>
 __device__ __forceinline__ void pass16(const Unit16& u, const Pre16& t, const float* Al, f32x4 (&acc)[TPW16][2]) {
-    Grp16 r0 = t.g[0], r1 = t.g[1], r2;
+    Grp16 r[RING16];
+    r[0] = t.g[0];
+    r[1] = t.g[1];
+#pragma unroll
+    for (int j = 2; j < RING16 - 1; ++j) load_grp16<T>(r[j], u, u.g0 + j);
     const int last = u.g1 - 1;
     int g = u.g0;
-    f32x4 a = *reinterpret_cast<const f32x4*>(Al + 16 * g);
-    f32x4 an = a;
-    for (; g + 3 <= u.g1; g += 3) {
-        load_grp16<T>(r2, u, g + 2);
-        an = *reinterpret_cast<const f32x4*>(Al + 16 * (g + 1));
-        mma_grp16<T>(a, r0, acc);
-        load_grp16<T>(r0, u, g + 3);
-        a = *reinterpret_cast<const f32x4*>(Al + 16 * (g + 2));
-        mma_grp16<T>(an, r1, acc);
-        load_grp16<T>(r1, u, g + 4);
-        an = *reinterpret_cast<const f32x4*>(Al + 16 * min(g + 3, last));
-        mma_grp16<T>(a, r2, acc);
-        a = an;
+    f32x4 a = lds_frag16(Al + 16 * g), an;
+    lds_frag16_wait();
+    for (; g + RING16 <= u.g1; g += RING16) {
+#pragma unroll
+        for (int s = 0; s < RING16; ++s) {
+            load_grp16<T>(r[(s + RING16 - 1) % RING16], u, g + s + RING16 - 1);
+            an = lds_frag16(Al + 16 * min(g + s + 1, last));
+            mma_grp16<T>(a, r[s], acc);
+            lds_frag16_wait();
+            a = an;
+        }
     }
-    const int rem = u.g1 - g;      // 0, 1 or 2 groups left, in r0 and r1
-    if (rem >= 1) {
-        an = *reinterpret_cast<const f32x4*>(Al + 16 * min(g + 1, last));
-        mma_grp16<T>(a, r0, acc);
+    const int rem = u.g1 - g;      // 0 .. RING16 - 1 groups left, all loaded
+#pragma unroll
+    for (int s = 0; s < RING16 - 1; ++s) {
+        if (s < rem) {
+            an = lds_frag16(Al + 16 * min(g + s + 1, last));
+            mma_grp16<T>(a, r[s], acc);
+            lds_frag16_wait();
+            a = an;
+        }
     }
-    if (rem >= 2) mma_grp16<T>(an, r1, acc);
 }
 
 // The first two k-groups of pass `pass` of the wave's work in layer L, unconditionally (a wave without work

@@ -33,8 +33,10 @@ from .nets import LayerSlot, Packed32, Shadow32Layout, Shadow32Slot, pad16, pad3
 LDS_PAD32 = 4
 SUPPORTED_HIDDEN_CHUNKS = (4, 8, 13)      # 4-row-tile phase kernels exist for hidden widths of 97..128, 225..256, 385..416
 #: batch size from which the 16x16x4 kernels (``csrc/mlp16_dev.h``, tiles of 16 rows) replace the 4x4x1 ones for the
-#: compiled widths (other widths always take them)
-WIDE_FROM_BATCH = 2048
+#: compiled widths (other widths always take them).  Measured, us per update, 4x4x1 / 16x16x4: Walker2d shape batch 1024
+#: 107 / 144, 2048 145 / 158 (128 tiles of 16 rows leave half the chip to the short roles of each launch), 4096
+#: 253 / 221; Ant shape batch 4096 301 / 238.
+WIDE_FROM_BATCH = 4096
 
 
 class HipCoreF32(HipCoreBf16):

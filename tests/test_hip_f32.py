@@ -36,7 +36,7 @@ CASES = [("d4pg", {}), ("d4pg", {"critic_loss": "ce", "dense_size": 128}), ("d3p
          ("d4pg", {"env": "BipedalWalker-v2", "batch_size": 2048, "phase_tile_rows": "16", "phase_mfma": "4x4"}),  # 16-row tiles
          ("d4pg", {"batch_size": 36, "phase_tile_rows": "4"}),                                # batch not a multiple of 32
          # the 16x16x4 kernels (csrc/mlp16_dev.h): large batches, and every hidden width the 4x4x1 kernels are not built for
-         ("d4pg", {"env": "BipedalWalker-v2", "batch_size": 2048}),
+         ("d4pg", {"env": "BipedalWalker-v2", "batch_size": 2048, "phase_mfma": "16x16"}),
          ("d4pg", {"env": "Ant-v2", "batch_size": 512, "phase_mfma": "16x16"}),               # 8 k-groups of input
          ("d4pg", {"dense_size": 64}),                                                        # hidden layers in K-slices
          ("d4pg", {"dense_size": 300}),
