@@ -103,6 +103,9 @@ def parse_args():
     ap.add_argument("--chunk", type=int, default=0,
                     help="updates per drawn-ahead chunk of batches = per graph replay (and per all-gather for N > 1); "
                          "0: the configuration default (sample_ahead)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the extra measurements beside the headline (N == 1: prioritised replay, the scalar critic and "
+                         "the Ant-shape batch-4096 stress in fp32; N > 1: rollout workers on ranks >= 1)")
     ap.add_argument("--dp-selftest", action="store_true",
                     help="with one GPU: run the N > 1 code path (both data-parallel modes) over a world-size-1 "
                          "RCCL group, to check the wiring on a single-GPU box")
@@ -135,7 +138,9 @@ def main() -> None:
         sys.exit(subprocess.call(cmd))
 
     from d4pg_pytorch_amd.config import default_config
+    from d4pg_pytorch_amd.models.core import build_core
     from d4pg_pytorch_amd.parallel.comm import LocalComm, TorchDistComm, attach_data_parallel, resolve_dp_mode
+    from d4pg_pytorch_amd.replay.hbm_replay import HbmReplay
 
     # one GPU per rank; ranks wrap around only when a multi-rank job is rehearsed on fewer GPUs
     # (D4PG_DIST_BACKEND=gloo, see parallel/comm.py)
@@ -200,6 +205,106 @@ def main() -> None:
             times.append(comm.all_reduce_max_scalar(time.perf_counter() - t0))
         times.sort()
         return times[len(times) // 2]
+
+
+    def quick_value(overrides, steps, warm):
+        """updates/s of a variation of the run's configuration (one GPU, no collectives): a short extra measurement."""
+        c = default_config(**{**cfg, **overrides, "num_steps_train": steps + warm + 64})
+        core_q = build_core(c, device)
+        rp = HbmReplay(c, device, core_q.dev_state)
+        core_q.attach_replay(rp)
+        Sq, Aq = c["state_dim"], c["action_dim"]
+        for off in range(0, 100_000, 50_000):
+            rp.insert(synthetic_rows(50_000, Sq, Aq, rp.row_ld, gamma_n, device, seed=77 + off))
+        many = getattr(core_q, "update_from_replay_many", None)
+
+        def run(total):
+            done = 0
+            while done < total:
+                if many is not None:
+                    done += many(total - done)
+                else:
+                    core_q.update_from_replay()
+                    done += 1
+        run(warm)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        run(steps)
+        torch.cuda.synchronize(device)
+        dt_q = time.perf_counter() - t0
+        del core_q, rp
+        torch.cuda.empty_cache()
+        return steps / dt_q
+
+    def rollout_workers_extra(seconds=4.0):
+        """N > 1: what the other GPUs buy as ROLLOUT devices.  Rank 0 is the learner (this run's per-rank
+        configuration, HBM replay); every other rank is a rollout worker (actors/rollout_worker.py) stepping 4096
+        device environments of the task on its own GPU, reading the online actor out of rank 0's HIP-IPC slots and
+        delivering its rows into rank 0's HBM (parallel/row_mailbox.py).  Returns environment steps/s of the job and
+        the learner's update rate beside that ingest."""
+        import torch.distributed as dist
+        from d4pg_pytorch_amd.parallel.ipc import ControlBlock
+        envs, seg = 4096, 32
+        rcfg = default_config(**{**cfg, "gpu_rollout_envs": envs, "gpu_rollout_segment": seg, "env_backend": "native",
+                                 "rollout_devices": list(range(1, world)), "replay_mem_size": 2_000_000,
+                                 "num_steps_train": 10 ** 9})
+        name = "d4pg_bench_roll_%s" % os.environ.get("MASTER_PORT", "0")
+        out = {}
+        if rank == 0:
+            from d4pg_pytorch_amd.models.learner import WeightPublisher
+            from d4pg_pytorch_amd.parallel.hip_ipc import SharedDeviceBuffer, write_handle
+            from d4pg_pytorch_amd.parallel.row_mailbox import RowMailbox
+            ctrl = ControlBlock.create(n_workers=world + 2, name=name)
+            core_r = build_core(rcfg, device)
+            rp = HbmReplay(rcfg, device, core_r.dev_state)
+            core_r.attach_replay(rp)
+            rp.insert(synthetic_rows(100_000, S, A, rp.row_ld, gamma_n, device, seed=5))
+            shared = SharedDeviceBuffer.create(4 * core_r.layout.actor.numel, device)
+            write_handle(ctrl.name, shared.handle, shared.numel, dev_index)
+            pub = WeightPublisher(core_r, None, ctrl, device, shared)
+            mailbox = RowMailbox.create(ctrl.name, world - 1, envs * seg, rp.row_ld, device)
+            pub.publish()
+            pub.poll(block=True)
+            dist.barrier()
+            many = core_r.update_from_replay_many
+            for _ in range(4):
+                many(32)
+            torch.cuda.synchronize(device)
+            rows0, t0, done, last_pub = mailbox.rows_received, time.perf_counter(), 0, 0
+            while time.perf_counter() - t0 < seconds:
+                done += many(32)
+                mailbox.poll(rp)
+                if done - last_pub >= 100:
+                    pub.publish()
+                    last_pub = done
+                pub.poll()
+            torch.cuda.synchronize(device)
+            el = time.perf_counter() - t0
+            pub.poll(block=True)
+            out = {"env_steps_per_sec": round((mailbox.rows_received - rows0) / el, 1),
+                   "learner_updates_per_sec_beside_rollouts": round(done / el, 2),
+                   "rollout_workers": world - 1, "rollout_envs_per_worker": envs, "rollout_segment_steps": seg,
+                   "rollout_env": env + " (native device simulator)"}
+            ctrl.request_stop()
+            dist.barrier()
+            mailbox.close()
+            shared.close()
+            for suffix in (".hipipc", ".rows.hipipc"):
+                try:
+                    os.unlink(os.path.join("/dev/shm", ctrl.name.strip("/") + suffix))
+                except OSError:
+                    pass
+            ctrl.close()
+        else:
+            from d4pg_pytorch_amd.actors.rollout_worker import run_rollout_worker
+            dist.barrier()                       # the control block, the weight handle and the mailbox exist
+            ctrl = ControlBlock.attach(name)
+            try:
+                run_rollout_worker(rcfg, ctrl, rank - 1, dev_index, hb_slot=rank)
+            finally:
+                dist.barrier()
+                ctrl.close()
+        return out
 
     extra = {}
     dp_mode = "none"
@@ -352,6 +457,24 @@ def main() -> None:
                     extra["speedup_vs_eager_torch"] = round(dt_e / (dt / args.steps), 2)
                 except Exception as exc:
                     extra["eager_torch_error"] = repr(exc)[:200]
+            if (args.dtype == "fp32" and not args.no_extras and not args.layers and not args.per
+                    and args.model == "d4pg" and env == "LunarLanderContinuous-v2" and args.batch == 256):
+                # the other headline configurations of the reference's algorithm family, fp32, same run (short):
+                # prioritised replay, the scalar critic (D3PG / DDPG) and the Ant-shape batch-4096 stress
+                metrics_primary = metrics_primary if metrics_primary is not None else core.read_metrics()
+                for key, ov, n_q, w_q in (("per_value", {"replay_memory_prioritized": 1}, 1600, 320),
+                                          ("d3pg_value", {"model": "d3pg"}, 1600, 320)):
+                    try:
+                        extra[key] = round(quick_value(ov, n_q, w_q), 2)
+                    except Exception as exc:
+                        extra[key + "_error"] = repr(exc)[:200]
+                try:
+                    ups = quick_value({"env": "Ant-v2", "batch_size": 4096, "v_min": 0.0, "v_max": 4000.0,
+                                       "state_dim": 111, "action_dim": 8}, 320, 96)
+                    extra["ant4096_fp32_ms_per_step"] = round(1000.0 / ups, 5)
+                    extra["ant4096_fp32_transitions_per_sec"] = round(ups * 4096, 1)
+                except Exception as exc:
+                    extra["ant4096_fp32_error"] = repr(exc)[:200]
         elif args.dp_mode != "both":
             dp_mode = args.dp_mode
             core, dt = run_replicated() if dp_mode == "replicated" else run_grad_allreduce()
@@ -388,10 +511,10 @@ def main() -> None:
 
             def give_up():
                 extra[other + "_error"] = "timed out"
-                extra["dp_mode_selected"] = dp_mode + " (the other mode did not finish)"
+                extra["dp_mode_selected"] = dp_mode + " (dp_mode: auto; the other mode did not finish)"
                 if rank == 0:
                     emit(core, dt, dp_mode, metrics_primary)
-                os._exit(0)
+                os._exit(4)          # the line above is valid, the job is not: a collective never completed
             watchdog = threading.Timer(max(180.0, 40.0 * dt * (repeats + 1) + 120.0), give_up)
             watchdog.daemon = True
             watchdog.start()
@@ -399,14 +522,38 @@ def main() -> None:
                 core_o, dt_o = runners[other]()
                 extra[other + "_value"] = round(args.steps / dt_o * world, 2)
                 extra[other + "_ms_per_step"] = round(1000.0 * dt_o / args.steps, 5)
-                if dt_o < dt:
-                    core, dt, dp_mode, metrics_primary = core_o, dt_o, other, core_o.read_metrics()
+                # `value` stays what dp_mode: auto runs; the faster of the two timed modes is reported beside it
+                faster, dt_f = (other, dt_o) if dt_o < dt else (auto, dt)
+                extra["faster_dp_mode"] = faster
+                extra["faster_dp_mode_value"] = round(args.steps / dt_f * world, 2)
             except Exception as exc:
                 extra[other + "_error"] = repr(exc)[:200]
             finally:
                 watchdog.cancel()
-            extra["dp_mode_selected"] = dp_mode + " (faster of the two timed modes)"
+            extra["dp_mode_selected"] = dp_mode + " (dp_mode: auto)"
 
+    if world > 1 and not args.no_extras and not args.baseline and not args.dp_selftest:
+        import threading
+        metrics_primary = metrics_primary if metrics_primary is not None else core.read_metrics()
+
+        def extras_hung():          # the headline must not be lost to an extra that never returns
+            extra["rollout_workers_error"] = "timed out"
+            if rank == 0:
+                emit(core, dt, dp_mode, metrics_primary)
+            os._exit(0)
+        import faulthandler
+        limit = float(os.environ.get("D4PG_BENCH_EXTRAS_TIMEOUT_S", "150"))
+        dog = threading.Timer(limit, extras_hung)
+        dog.daemon = True
+        dog.start()
+        faulthandler.dump_traceback_later(max(1.0, limit - 5.0), exit=False)     # a hang names its own stack on stderr
+        try:
+            extra.update(rollout_workers_extra())
+        except Exception as exc:
+            extra["rollout_workers_error"] = repr(exc)[:300]
+        finally:
+            faulthandler.cancel_dump_traceback_later()
+            dog.cancel()
     emit(core, dt, dp_mode, metrics_primary)
     comm.close()
 

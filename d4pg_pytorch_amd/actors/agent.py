@@ -116,12 +116,15 @@ class Agent:
             v = self.ctrl.load(ControlBlock.GPU_WEIGHT_VERSION)
             if v == self._gpu_version:
                 return False
-            while True:                   # a slot is rewritten two publications later: repack if that overtook us
-                self.actor.refresh_shared(v)
-                v2 = self.ctrl.load(ControlBlock.GPU_WEIGHT_VERSION)
-                if v2 < v + 2:
+            for _ in range(3):
+                self.actor.refresh_shared(v)      # (synchronises: the pack has read the slot when it returns)
+                # The slot of publication v is rewritten by publication v + 2, whose copies are enqueued before the
+                # version counter moves: the pack was overtaken iff that publication had been ISSUED by now.  Two
+                # more attempts at most: past that a policy torn between consecutive versions is accepted, as the
+                # reference's exploiter does on every step (unsynchronised shared memory).
+                if self.ctrl.load(ControlBlock.GPU_WEIGHT_ISSUED) < v + 2 or self.ctrl.stop:
                     break
-                v = v2
+                v = max(v, self.ctrl.load(ControlBlock.GPU_WEIGHT_VERSION))
             self._gpu_version = v
             self.weight_versions_seen += 1
             return True

@@ -41,11 +41,17 @@ class PackedActor32:
         self.device = torch.device(device)
         self.layout = NetLayout.build(state_dim, hidden, action_dim)
         waves = H.lib().d4pg_phase32_waves()
+        # hidden widths the 4x4x1 kernels are compiled for take them; every other width the 16x16x4 kernel
+        # (csrc/mlp16_dev.h: any width at run time, tiles of 8 / 16 environments)
+        self.wide = not (pad32(hidden) // 32 in FUSED_HIDDEN_CHUNKS and pad32(state_dim) <= 128)
         off = 0
         self.packed = []
         for i, s in enumerate(self.layout.layers):
-            nt, ks, ksplit, nch = Packed32.geometry(s.out_dim, s.in_dim, i == 2, waves)
-            p = Packed32(off, s.out_dim, s.in_dim, nt, ks, ksplit, nch)
+            if self.wide:
+                nt, ks, ksplit, nch = Packed32.geometry_wide(s.out_dim, s.in_dim, waves)
+            else:
+                nt, ks, ksplit, nch = Packed32.geometry(s.out_dim, s.in_dim, i == 2, waves)
+            p = Packed32(off, s.out_dim, s.in_dim, nt, ks, ksplit, nch, self.wide)
             off += p.numel
             self.packed.append(p)
         self.bias_off = []
@@ -53,12 +59,17 @@ class PackedActor32:
             self.bias_off.append(off)
             off += pad16(s.out_dim)
         self.buf = torch.zeros(off, dtype=torch.float32, device=self.device)
-        self.ldx = pad32(state_dim) + LDS_PAD32
-        self.ldh = 32 * max(self.packed[1].ks, self.packed[2].ks) + LDS_PAD32
+        if self.wide:
+            self.ldx = pad16(state_dim) + LDS_PAD32
+            self.ldh = pad16(hidden) + LDS_PAD32
+        else:
+            self.ldx = pad32(state_dim) + LDS_PAD32
+            self.ldh = 32 * max(self.packed[1].ks, self.packed[2].ks) + LDS_PAD32
 
     @staticmethod
     def supported(state_dim: int, action_dim: int, hidden: int) -> bool:
-        return pad32(hidden) // 32 in FUSED_HIDDEN_CHUNKS and action_dim <= 64 and pad32(state_dim) <= 128
+        """One launch per batch of states: any hidden width whose two activation tiles of 8 rows fit the LDS."""
+        return action_dim <= 64 and 8 * 4 * (pad16(state_dim) + 2 * pad16(hidden) + 12) + 7 * 1024 <= 160 * 1024
 
     def pack_from(self, src_ptr: int, actor_base: int = 0, stream=None) -> None:
         """Rebuild the packed copies from flat actor parameters at device address ``src_ptr`` (floats, the
@@ -70,6 +81,7 @@ class PackedActor32:
             m.src_off, m.bias_off = actor_base + s.w_off, actor_base + s.b_off
             m.dst_off, m.dst_bias = p.off, self.bias_off[i]
             m.out_dim, m.in_dim, m.ld, m.ks = s.out_dim, s.in_dim, s.ld, p.ks
+        a.wide = int(self.wide)
         H.launch("d4pg_pack_actor32", a, stream)
 
     def infer_args(self, obs: torch.Tensor, act: torch.Tensor, n: int, action_scale: float = 1.0) -> H.ActorInferArgs32:
@@ -90,6 +102,15 @@ class PackedActor32:
     def tile_rows(n: int) -> int:
         """Rows per workgroup / 4: 4-row tiles while their workgroups fit the chip (see models/hip_core_f32.py)."""
         return 1 if n <= 1024 else (2 if n <= 2048 else 4)
+
+    def infer(self, a: "H.ActorInferArgs32", n: int) -> None:
+        """Enqueue the inference launch described by ``a`` (:meth:`infer_args`) for ``n`` rows."""
+        if self.wide:
+            lds16 = 16 * 4 * (self.ldx + 2 * self.ldh) + 7 * 1024
+            mt = 4 if (n > 8 and lds16 <= 160 * 1024) else 2
+            H._check(H.lib().d4pg_actor_infer32w(a, mt, H.stream_ptr()), "d4pg_actor_infer32w")
+        else:
+            H._check(H.lib().d4pg_actor_infer32(a, self.tile_rows(n), H.stream_ptr()), "d4pg_actor_infer32")
 
 
 class GpuActor:
@@ -156,8 +177,7 @@ class GpuActor:
         n = obs.shape[0]
         out = self.out[:n] if out is None else out
         if self.fused is not None:
-            a = self.fused.infer_args(obs, out, n, self.action_scale)
-            H._check(H.lib().d4pg_actor_infer32(a, PackedActor32.tile_rows(n), H.stream_ptr()), "d4pg_actor_infer32")
+            self.fused.infer(self.fused.infer_args(obs, out, n, self.action_scale), n)
             return out
         (w1, b1, s1), (w2, b2, s2), (w3, b3, s3) = self._slot(0), self._slot(1), self._slot(2)
         H.gemm_group([H.gemm_desc(H.GEMM_NT, obs, obs.shape[1], w1, s1.ld, self.h1, self.ldh, n, self.Hd, self.S,

@@ -36,10 +36,20 @@ class DeviceRollout:
         self.S, self.A = int(cfg["state_dim"]), int(cfg["action_dim"])
         assert env.state_dim == self.S and env.action_dim == self.A
         if not PackedActor32.supported(self.S, self.A, int(cfg["dense_size"])):
-            raise ValueError("the device rollout needs a hidden width the single-launch inference kernel supports")
+            raise ValueError("the device rollout needs a policy the single-launch inference kernel supports (<= 64 actions)")
         self.actor = PackedActor32(self.S, self.A, int(cfg["dense_size"]), self.device)
         self.explore = bool(explore)
         self.n, self.gamma = int(cfg["n_step_returns"]), float(cfg["discount_rate"])
+        if self.explore and float(cfg["ou_min_sigma"]) != float(cfg["ou_max_sigma"]):
+            # the host agents anneal sigma over ou_decay_period steps of an episode (utils/utils.py:32 of the
+            # reference); the noise kernel here takes one sigma, so a schedule would silently train differently
+            raise ValueError("device explorers draw OU noise with a constant sigma: set ou_min_sigma == ou_max_sigma "
+                             "(the reference's own setting) or use host explorers")
+        if int(segment) < 4 * self.n:
+            import warnings
+            warnings.warn(f"gpu_rollout_segment={segment} with n_step_returns={self.n}: the last n - 1 steps of every "
+                          f"segment bootstrap early, i.e. {100.0 * (self.n - 1) / int(segment):.0f} % of the rows "
+                          f"(use a segment of at least {4 * self.n} steps to keep that below 25 %)", stacklevel=2)
         self.action_scale = float(cfg["action_high"]) if cfg.get("scale_action") else 1.0
         T, E, S = self.T, self.E, self.S
         self.lda = 4 * ((self.A + 3) // 4)
@@ -95,10 +105,8 @@ class DeviceRollout:
     def _enqueue_segment(self) -> None:
         T, E = self.T, self.E
         self.obs[0].copy_(self.obs[T])
-        mt = PackedActor32.tile_rows(E)
         for t in range(T):
-            a = self.actor.infer_args(self.obs[t], self.act_raw, E, self.action_scale)
-            H._check(H.lib().d4pg_actor_infer32(a, mt, H.stream_ptr()), "d4pg_actor_infer32")
+            self.actor.infer(self.actor.infer_args(self.obs[t], self.act_raw, E, self.action_scale), E)
             self._ou(t)
             self.env.step(self.act[t], self.obs[t + 1], self.next_obs[t], self.reward[t], self.done[t], self.trunc[t])
         na = H.NstepArgs()

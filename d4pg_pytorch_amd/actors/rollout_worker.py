@@ -54,6 +54,14 @@ def run_rollout_worker(config: Dict, ctrl: ControlBlock, k: int, device_index: i
         raise ValueError(f"rollout_devices: no device-resident implementation of '{cfg['env']}'")
     rollout = DeviceRollout(cfg, env, _RowShape(cfg["state_dim"], cfg["action_dim"]), device, segment=segment, seed=seed)
 
+    import os
+    import sys
+    debug = bool(os.environ.get("D4PG_DEBUG_WORKER"))
+
+    def note(msg: str) -> None:
+        if debug:
+            print(f"[rollout worker {k} {time.time() % 1000:8.3f}] {msg}", file=sys.stderr, flush=True)
+
     def beat() -> None:
         ctrl.heartbeat(hb_slot, int(time.time() * 1000))
 
@@ -85,23 +93,30 @@ def run_rollout_worker(config: Dict, ctrl: ControlBlock, k: int, device_index: i
                 time.sleep(0.002)            # nothing to act with before the learner's first publication
                 continue
             if v != version:
+                note(f"pack version {v} (had {version}), segment {segments}")
                 with torch.cuda.stream(rollout.stream):
-                    while True:
+                    for _ in range(3):
                         base = ((v - 1) % 2) * 2 * n_actor       # the online half of the slot of publication v
                         rollout.actor.pack_from(shared.ptr, base)
                         rollout.stream.synchronize()
-                        # a slot is rewritten by the publication two after its own: pack again if that one was
-                        # issued while this pack ran
-                        if ctrl.load(ControlBlock.GPU_WEIGHT_ISSUED) < v + 2:
+                        # A slot is rewritten by the publication two after its own: pack again if that one was
+                        # issued while this pack ran.  At most twice: a learner that publishes faster than a pack
+                        # takes (two processes sharing one GPU) must not starve the explorers, and a policy torn
+                        # between two consecutive versions is what the reference's exploiter reads all the time
+                        # (models/d4pg/engine.py:134, unsynchronised shared memory).
+                        if ctrl.load(ControlBlock.GPU_WEIGHT_ISSUED) < v + 2 or ctrl.stop:
                             break
-                        v = ctrl.load(ControlBlock.GPU_WEIGHT_VERSION)
+                        v = max(v, ctrl.load(ControlBlock.GPU_WEIGHT_VERSION))
                 version = v
+                note("packed")
             rollout.launch()
             rollout.done_event.synchronize()
+            note("segment done")
             rollout.drain(insert=False)
             with torch.cuda.stream(rollout.stream):
                 if not mailbox.push(k, rollout.rows, should_stop=stopping):
                     break
+            note("pushed")
             n = n_envs * segment
             delivered += n
             segments += 1

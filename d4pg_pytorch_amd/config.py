@@ -93,6 +93,10 @@ EXTENSION_DEFAULTS: Dict[str, Any] = {
                                      # "numpy" = the fp64 simulator written out in numpy (envs/planar.py), "auto" = native if built
     "gpu_rollout_envs": 0,           # > 0: that many explorer environments stepped ON the learner's GPU (policy, noise,
                                      # dynamics, n-step rows and replay insert without a host hop; envs/device_pendulum.py)
+    "rollout_devices": None,         # list of GPU indices: one ROLLOUT WORKER process per entry (actors/rollout_worker.py) steps
+                                     # gpu_rollout_envs device environments on THAT GPU, reads the online actor out of the
+                                     # learner's HIP-IPC slots and delivers its rows into the learner's HBM (peer write over
+                                     # xGMI + one replay_insert); None / []: the device explorers run inside the learner
     "gpu_rollout_segment": 32,       # environment steps per captured rollout segment
     "gpu_rollout_interval": 32,      # learner updates between two segments
     "share_weights_ipc": True,       # GPU agents read the learner's weights in place through HIP IPC
@@ -126,6 +130,8 @@ EXTENSION_DEFAULTS: Dict[str, Any] = {
     "resume": None,                  # path to a learner checkpoint bundle to resume from
     "learner_checkpoint_interval": 0,  # 0 = only at the end
     "heartbeat_timeout_s": 120.0,
+    "max_restarts_per_process": 3,   # crashed / hung agents and rollout workers are replaced this many times EACH ...
+    "max_restarts_per_hour": 20,     # ... and the job gives up only if replacements come faster than this overall
     "log_backend": "tb",             # "tb" (TensorBoard event files) | "jsonl" | "both"
     "check_rings": False,            # race detection (train.py --check): every ring slot carries the running index of
                                      # its row; the consumer verifies it, the run fails on a mismatch
@@ -161,6 +167,7 @@ _INT_KEYS = {
     "dense_size", "num_atoms", "num_learners", "envs_per_agent", "weight_publish_interval",
     "max_env_steps_per_agent", "metrics_interval", "ring_capacity", "ingest_chunk", "ingest_interval", "sample_ahead", "control_interval",
     "ou_decay_period", "learner_checkpoint_interval", "gpu_rollout_envs", "gpu_rollout_segment", "gpu_rollout_interval",
+    "max_restarts_per_process", "max_restarts_per_hour",
 }
 _FLOAT_KEYS = {
     "action_low", "action_high", "priority_alpha", "priority_beta_start", "priority_beta_end",
@@ -279,6 +286,14 @@ def finalize_config(raw: Dict[str, Any]) -> Dict[str, Any]:
     need(cfg["gpu_rollout_envs"] >= 0 and cfg["gpu_rollout_segment"] >= 1 and cfg["gpu_rollout_interval"] >= 1,
          "gpu_rollout_envs must be >= 0, gpu_rollout_segment and gpu_rollout_interval >= 1")
     need(cfg["gpu_rollout_envs"] == 0 or str(cfg["device"]).startswith("cuda"), "gpu_rollout_envs needs device: cuda")
+    if cfg["rollout_devices"] in (None, "", []):
+        cfg["rollout_devices"] = []
+    elif isinstance(cfg["rollout_devices"], (int, str)):
+        cfg["rollout_devices"] = [int(x) for x in str(cfg["rollout_devices"]).strip("[]").split(",") if x.strip()]
+    else:
+        cfg["rollout_devices"] = [int(x) for x in cfg["rollout_devices"]]
+    need(not cfg["rollout_devices"] or cfg["gpu_rollout_envs"] > 0, "rollout_devices needs gpu_rollout_envs > 0")
+    need(all(d >= 0 for d in cfg["rollout_devices"]), "rollout_devices must be GPU indices")
     need(cfg["critic_loss"] in ("bce", "ce"), "critic_loss must be 'bce' or 'ce'")
     need(cfg["compute_dtype"] in ("auto", "fp32", "bf16"), "compute_dtype must be 'auto', 'fp32' or 'bf16'")
     need(cfg["replay_device"] in ("auto", "hbm", "host"), "replay_device must be auto|hbm|host")

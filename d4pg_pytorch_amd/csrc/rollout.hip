@@ -14,6 +14,7 @@
 
 #include "common.h"
 #include "mlp32_dev.h"
+#include "mlp16_dev.h"
 
 struct PackMat32 {
     long long src_off;     // W[out][ld] inside the flat source (floats)
@@ -26,6 +27,8 @@ struct PackActorArgs32 {
     const float* src;
     float* dst;
     PackMat32 m[3];
+    int wide;              // packed copies in the order of csrc/mlp16_dev.h (ks = 16-wide k-groups)
+    int pad_;
 };
 
 __global__ __launch_bounds__(256) void pack_actor32_kernel(const PackActorArgs32 a) {
@@ -33,14 +36,14 @@ __global__ __launch_bounds__(256) void pack_actor32_kernel(const PackActorArgs32
     const long long n = (long long)m.out_dim * m.in_dim;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int o = (int)(i / m.in_dim), k = (int)(i - (long long)o * m.in_dim);
-        a.dst[m.dst_off + packed32_off(o, k, m.ks)] = a.src[m.src_off + (long long)o * m.ld + k];
+        a.dst[m.dst_off + (a.wide ? packed16_off(o, k, m.ks) : packed32_off(o, k, m.ks))] = a.src[m.src_off + (long long)o * m.ld + k];
         if (k == 0) a.dst[m.dst_bias + o] = a.src[m.bias_off + o];
     }
 }
 D4PG_API int d4pg_pack_actor32(const PackActorArgs32* a, hipStream_t stream) {
     if (a->src == nullptr || a->dst == nullptr) return -1;
     for (int i = 0; i < 3; ++i)
-        if (a->m[i].out_dim < 1 || a->m[i].in_dim < 1 || a->m[i].ld < a->m[i].in_dim || a->m[i].ks * 32 < a->m[i].in_dim) return -2;
+        if (a->m[i].out_dim < 1 || a->m[i].in_dim < 1 || a->m[i].ld < a->m[i].in_dim || a->m[i].ks * (a->wide ? 16 : 32) < a->m[i].in_dim) return -2;
     hipLaunchKernelGGL(pack_actor32_kernel, dim3(160, 3), dim3(256), 0, stream, *a);
     return (int)hipGetLastError();
 }

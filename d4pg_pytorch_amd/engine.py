@@ -161,6 +161,13 @@ def agent_worker(config: Dict, ctrl_name: str, slab_name: str, ring_name: Option
     agent.run()
 
 
+def rollout_worker_entry(config: Dict, ctrl_name: str, k: int, device_index: int, hb_slot: int) -> None:
+    """Device-resident explorers on GPU ``device_index`` (``actors/rollout_worker.py``)."""
+    from .actors.rollout_worker import rollout_worker
+    _set_threads(1)
+    rollout_worker(config, ctrl_name, k, device_index, hb_slot)
+
+
 # --------------------------------------------------------------------------- engine
 class Engine:
     def __init__(self, config: Dict):
@@ -197,7 +204,8 @@ class Engine:
         from .models.nets import NetLayout
         from .replay.hbm_replay import row_ld
         n_actor = NetLayout.build(cfg["state_dim"], cfg["dense_size"], cfg["action_dim"]).numel
-        ctrl = ControlBlock.create(n_workers=world + total_agents + 2)
+        rollout_devices = list(cfg.get("rollout_devices") or []) if str(cfg["device"]).startswith("cuda") else []
+        ctrl = ControlBlock.create(n_workers=world + total_agents + 2 + len(rollout_devices))
         slab = WeightSlab.create(2 * n_actor)
         rings: List[ShmRing] = []
         names = [ctrl.name, slab.name]
@@ -208,6 +216,7 @@ class Engine:
         self.hb_slots = {f"learner-{r}": r for r in range(world)}
         self.hb_slots.update({f"agent-{i}": world + i for i in range(total_agents)})
         self.hb_slots["sampler"] = world + total_agents
+        self.hb_slots.update({f"rollout-{k}": world + total_agents + 1 + k for k in range(len(rollout_devices))})
         try:
             rl = row_ld(cfg["state_dim"], cfg["action_dim"])
             for _ in range(world * n_explorers_per_rank):
@@ -233,6 +242,8 @@ class Engine:
             for i in range(world * n_explorers_per_rank):
                 specs[f"agent-{i + 1}"] = (agent_worker, (cfg, ctrl.name, slab.name, ring_names[i], i + 1,
                                                           "exploration", exp_dir, self.hb_slots[f"agent-{i + 1}"]))
+            for k, dev_index in enumerate(rollout_devices):
+                specs[f"rollout-{k}"] = (rollout_worker_entry, (cfg, ctrl.name, k, int(dev_index), self.hb_slots[f"rollout-{k}"]))
             # learners first: agents block on nothing, but fresh weights should exist early
             for name, (fn, args) in specs.items():
                 procs[name] = self._spawn(ctx, name, fn, args)
@@ -266,10 +277,11 @@ class Engine:
             for r in rings:
                 r.close()
             slab.close()
-            try:
-                os.unlink(os.path.join("/dev/shm", ctrl.name.strip("/") + ".hipipc"))    # device weight handle
-            except OSError:
-                pass
+            for suffix in (".hipipc", ".rows.hipipc"):       # device weight handle, row staging ring of rollout workers
+                try:
+                    os.unlink(os.path.join("/dev/shm", ctrl.name.strip("/") + suffix))
+                except OSError:
+                    pass
             ctrl.close()
             cleanup_names(names)
         if failed:
@@ -279,7 +291,24 @@ class Engine:
     def _supervise(self, ctx, procs: Dict[str, mp.Process], specs: Dict[str, tuple], ctrl: ControlBlock) -> None:
         cfg = self.config
         hb_timeout_ms = float(cfg["heartbeat_timeout_s"]) * 1000.0
-        max_restarts = 3
+        # A replaceable process (agent, rollout worker) may be replaced `max_restarts_per_process` times; the job
+        # gives up on one that exceeds it, or when replacements come faster than `max_restarts_per_hour` overall
+        # (one flaky explorer in a day-long run is not a reason to end it).
+        per_proc = int(cfg.get("max_restarts_per_process", 3))
+        per_hour = int(cfg.get("max_restarts_per_hour", 20))
+        counts: Dict[str, int] = {}
+        recent: List[float] = []
+
+        def may_restart(name: str) -> bool:
+            now = time.time()
+            recent[:] = [t for t in recent if now - t < 3600.0]
+            if counts.get(name, 0) >= per_proc or len(recent) >= per_hour:
+                return False
+            counts[name] = counts.get(name, 0) + 1
+            recent.append(now)
+            self.restarts += 1
+            return True
+
         while True:
             time.sleep(0.05)
             if ctrl.stop:
@@ -296,9 +325,8 @@ class Engine:
                     ctrl.request_stop()
                     return
                 if code != 0 and not ctrl.stop:
-                    if self.restarts < max_restarts:
-                        self.restarts += 1
-                        print(f"[engine] {name} crashed (exit {code}); restart {self.restarts}/{max_restarts}", flush=True)
+                    if may_restart(name):
+                        print(f"[engine] {name} crashed (exit {code}); restart {counts[name]}/{per_proc}", flush=True)
                         fn, args = specs[name]
                         procs[name] = self._spawn(ctx, name, fn, args)
                     else:
@@ -327,8 +355,7 @@ class Engine:
                 p.join(timeout=5.0)
                 ctrl.heartbeat(slot, 0)
                 self.hung_killed += 1
-                if self.restarts < max_restarts:
-                    self.restarts += 1
+                if may_restart(name):
                     fn, args = specs[name]
                     procs[name] = self._spawn(ctx, name, fn, args)
                 else:

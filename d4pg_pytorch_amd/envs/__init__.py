@@ -41,7 +41,10 @@ def create_env_wrapper(config, num_envs=None, seed=None) -> VecEnv:
         return SyntheticVec(name, E, S, A, lo, hi, seed, episode_len=config["max_ep_length"])
     if name in ("Pendulum-v0", "Pendulum-v1"):
         return PendulumVec(E, seed, env_name=name)
-    if gym_available():
+    # Device explorers (gpu_rollout_envs > 0) step the NATIVE task; the host agents of such a job must play the same
+    # dynamics, so gym is not used then (nor with env_backend: native) even where it is installed.
+    native_only = int(config.get("gpu_rollout_envs") or 0) > 0 or config.get("env_backend") == "native"
+    if gym_available() and not native_only:
         try:
             return GymVec(name, E, S, A, lo, hi, seed, REWARD_SCALE.get(name, 1.0))
         except Exception as exc:   # unknown id, missing simulator backend, ...

@@ -234,7 +234,8 @@ def make_device_env(cfg, num_envs: int, device, seed: int = 0):
     if name.startswith("Pendulum"):
         return DevicePendulum(num_envs, device, seed, time_limit=min(200, limit))
     from .gym_adapter import gym_available
-    if gym_available():
+    if gym_available() and int(cfg.get("gpu_rollout_envs") or 0) <= 0 and cfg.get("env_backend") != "native":
+        # the host agents of this job would play gym's dynamics (envs.create_env_wrapper): no native twin to offer
         return None
     if name == "InvertedPendulum-v2":
         return DeviceCartPole(num_envs, device, seed, time_limit=limit)

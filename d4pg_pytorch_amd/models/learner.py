@@ -204,6 +204,7 @@ class WeightPublisher:
         main = torch.cuda.current_stream(self.device)
         if self.read_done[slot] is not None:
             main.wait_event(self.read_done[slot])
+        self.ctrl.store(ControlBlock.GPU_WEIGHT_ISSUED, self.issued + 1)     # before the slot is touched
         with torch.no_grad():
             self.stage[slot, :n].copy_(core.online.actor_flat().detach(), non_blocking=True)
             self.stage[slot, n:].copy_(core.target.actor_flat().detach(), non_blocking=True)
@@ -276,7 +277,7 @@ class Learner:
         self.hb_slot = rank                      # heartbeat slot of this learner rank (engine.py: learners come first)
         self._shared = None
         if (rank == 0 and self.device.type == "cuda" and config.get("share_weights_ipc", True)
-                and str(config.get("exploiter_device", "cpu")).startswith("cuda")):
+                and (str(config.get("exploiter_device", "cpu")).startswith("cuda") or config.get("rollout_devices"))):
             self._shared = self._export_weights()
         self.publisher = WeightPublisher(self.core, slab, ctrl, self.device, self._shared) if rank == 0 else None
         self.rollout = None
@@ -392,6 +393,7 @@ class Learner:
         min_rows = max(int(cfg["min_replay_size"]), int(cfg["batch_size"]))
         ingest_every = max(1, int(cfg.get("ingest_interval", 32)))     # updates between two ring drains
         self.rollout = self._make_rollout(replay)
+        mailbox = self._make_mailbox(replay)
         rollout_every = max(1, int(cfg.get("gpu_rollout_interval", 32)))
         last_rollout = -rollout_every
         self.publish_weights(wait=True)
@@ -426,7 +428,7 @@ class Learner:
         control_every = max(1, int(cfg.get("control_interval", 1024)))
         while core.step < self.num_train_steps and not (ctrl.stop and world == 1):
             if len(replay) < min_rows or self._throttle():
-                moved = ingest.poll()
+                moved = ingest.poll() + (mailbox.poll(replay) if mailbox is not None else 0)
                 if moved and dp is not None:
                     dp.mark_inserted()
                 if self.rollout is not None:
@@ -442,7 +444,7 @@ class Learner:
             prev = core.step
             if prev % ingest_every == 0 or prev // ingest_every != last_ingest // ingest_every:
                 last_ingest = prev
-                if ingest.poll() and dp is not None:
+                if ingest.poll() + (mailbox.poll(replay) if mailbox is not None else 0) and dp is not None:
                     dp.mark_inserted()
             if self.rollout is not None and prev - last_rollout >= rollout_every:
                 last_rollout = prev
@@ -455,6 +457,9 @@ class Learner:
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
         ingest.close()
+        if mailbox is not None:
+            self.rows_from_workers = mailbox.rows_received
+            mailbox.close()
         if dp is not None:
             drift = dp.check_consistency()
             if drift != 0.0:
@@ -463,12 +468,25 @@ class Learner:
             replay.dump(os.path.join(cfg["results_path"], "replay_buffer.pkl"))
         self._finish()
 
+    def _make_mailbox(self, replay):
+        """Staging ring in this GPU's memory for the rows of rollout workers on other GPUs (``rollout_devices``);
+        learner rank 0 only: every worker of the job delivers here."""
+        cfg = self.config
+        devs = cfg.get("rollout_devices") or []
+        if not devs or self.rank != 0 or self.device.type != "cuda":
+            return None
+        if self._shared is None:
+            raise RuntimeError("rollout_devices needs the learner's weights shared through HIP IPC (share_weights_ipc)")
+        from ..parallel.row_mailbox import RowMailbox
+        rows = int(cfg["gpu_rollout_envs"]) * int(cfg.get("gpu_rollout_segment", 32))
+        return RowMailbox.create(self.ctrl.name, len(devs), rows, replay.row_ld, self.device)
+
     def _make_rollout(self, replay):
         """Explorers resident on this GPU (``gpu_rollout_envs`` > 0 and the environment exists as device
         kernels): they fill the replay next to, or instead of, the CPU explorer processes."""
         cfg = self.config
         n_envs = int(cfg.get("gpu_rollout_envs") or 0)
-        if n_envs <= 0 or self.device.type != "cuda":
+        if n_envs <= 0 or self.device.type != "cuda" or cfg.get("rollout_devices"):
             return None
         from ..actors.gpu_rollout import DeviceRollout
         from ..envs.device_envs import make_device_env

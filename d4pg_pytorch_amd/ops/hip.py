@@ -275,7 +275,7 @@ class PackMat32(C.Structure):
 
 
 class PackActorArgs32(C.Structure):
-    _fields_ = [("src", vp), ("dst", vp), ("m", PackMat32 * 3)]
+    _fields_ = [("src", vp), ("dst", vp), ("m", PackMat32 * 3), ("wide", C.c_int), ("pad_", C.c_int)]
 
 
 class PendulumArgs(C.Structure):

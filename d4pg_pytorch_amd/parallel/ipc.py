@@ -278,6 +278,9 @@ class ControlBlock(_Shm):
     STOP, UPDATE_STEP, GLOBAL_EPISODE, ENV_STEPS, LEARNER_ALIVE, FAILED = range(6)
     #: device-resident weight hand-off (parallel/hip_ipc.py): completed publications / learner step of the newest
     GPU_WEIGHT_VERSION, GPU_WEIGHT_STEP = 6, 7
+    #: publications whose device-to-device copies have been ENQUEUED (>= completed).  Publication p (1-based) writes
+    #: slot (p - 1) % 2, so a reader of publication v was overtaken iff this reads >= v + 2 when its pack has finished.
+    GPU_WEIGHT_ISSUED = 8
     N_FIXED = 16
 
     @classmethod

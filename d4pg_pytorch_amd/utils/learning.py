@@ -61,7 +61,7 @@ class GreedyEvaluator:
         from ..actors.gpu_actor import PackedActor32
         from ..envs.device_envs import make_device_env
         self.device = torch.device(device)
-        self.env = make_device_env(cfg, envs, device, seed)
+        self.env = make_device_env(dict(cfg, env_backend="native"), envs, device, seed)      # (never gym: evaluation on the device)
         S, A = self.env.state_dim, self.env.action_dim
         self.actor = PackedActor32(S, A, int(cfg["dense_size"]), device)
         self.scale = float(cfg["action_high"]) if cfg.get("scale_action") else 1.0
@@ -78,11 +78,9 @@ class GreedyEvaluator:
         self.env.reset(self.obs)
         self.first.zero_()
         self.alive.fill_(1.0)
-        mt = PackedActor32.tile_rows(self.env.E)
         scale = float(getattr(self.env, "reward_scale", 1.0))
         for _ in range(self.env.time_limit):
-            a = self.actor.infer_args(self.obs, self.act, self.env.E, self.scale)
-            H._check(H.lib().d4pg_actor_infer32(a, mt, H.stream_ptr()), "d4pg_actor_infer32")
+            self.actor.infer(self.actor.infer_args(self.obs, self.act, self.env.E, self.scale), self.env.E)
             self.env.step(self.act, self.obs, self.nobs, self.rew, self.done, self.trunc)
             self.first.add_(self.rew * self.alive, alpha=scale)          # rewards of the first episode only
             self.alive.mul_(1.0 - torch.clamp(self.done + self.trunc, max=1.0))
@@ -115,7 +113,7 @@ def train_on_device(model: str = "d4pg", core: str = "fp32", updates: int = 20_0
     if fused:
         c.attach_replay(rp)
     sampler = None if fused else _TorchSampler(rp, int(cfg["batch_size"]), seed)
-    ro = DeviceRollout(cfg, make_device_env(cfg, envs, device, seed + 1), rp, device, segment=segment, seed=seed + 2)
+    ro = DeviceRollout(cfg, make_device_env(dict(cfg, env_backend="native"), envs, device, seed + 1), rp, device, segment=segment, seed=seed + 2)
     ev = GreedyEvaluator(cfg, eval_envs, device, seed + 3)
     base_a = c.layout.actor.base
     for _ in range(warmup_segments):            # random-ish data before the first update (min_replay_size)

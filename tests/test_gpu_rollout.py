@@ -24,13 +24,14 @@ def _torch_policy(pol, x):
 
 
 @pytest.mark.parametrize("S,A,Hd,E", [(24, 4, 400, 48), (3, 1, 400, 1), (8, 2, 128, 37), (17, 6, 256, 1500),
-                                      (111, 8, 400, 4100), (24, 4, 72, 9)])
+                                      (111, 8, 400, 4100), (24, 4, 72, 9), (17, 6, 300, 700), (8, 2, 1024, 40)])
 def test_gpu_actor_single_launch_matches_fp32_reference(S, A, Hd, E):
     from d4pg_pytorch_amd.actors.gpu_actor import GpuActor
     pol = _policy(S, A, Hd)
     gpu = GpuActor(S, A, Hd, max_batch=E, action_scale=1.5)
     gpu.load_flat(pol.flat.numpy())
-    assert gpu.launches_per_act == (3 if Hd == 72 else 1)
+    assert gpu.launches_per_act == 1          # every width: the 16x16x4 kernel takes what the 4x4x1 kernels are not built for
+    assert gpu.fused.wide == (Hd in (72, 300, 1024))
     x = torch.randn(E, S, generator=torch.Generator().manual_seed(2))
     want = 1.5 * _torch_policy(pol, x.double().float())
     got = gpu.act(x.numpy())
@@ -39,11 +40,12 @@ def test_gpu_actor_single_launch_matches_fp32_reference(S, A, Hd, E):
     np.testing.assert_allclose(gpu.act(x[:k].numpy()), want[:k].numpy(), rtol=1e-4, atol=2e-6)
 
 
-def test_pack_kernel_equals_host_packing():
+@pytest.mark.parametrize("Hd", [400, 300])
+def test_pack_kernel_equals_host_packing(Hd):
     from d4pg_pytorch_amd.actors.gpu_actor import PackedActor32
     from d4pg_pytorch_amd.models.nets import pack32
-    pol = _policy(24, 4, 400)
-    pa = PackedActor32(24, 4, 400, "cuda")
+    pol = _policy(24, 4, Hd)
+    pa = PackedActor32(24, 4, Hd, "cuda")
     flat = pol.flat.cuda()
     pa.pack_from(flat.data_ptr())
     torch.cuda.synchronize()
@@ -248,7 +250,7 @@ def test_rollout_with_terminal_states_equals_the_host_nstep_assembler():
     from d4pg_pytorch_amd.models.core import build_core
     from d4pg_pytorch_amd.replay.hbm_replay import HbmReplay
     cfg = default_config(env="InvertedPendulum-v2", model="d3pg", batch_size=64, dense_size=128, device="cuda",
-                         n_step_returns=5, replay_mem_size=20_000, ou_max_sigma=1.0, random_seed=3)
+                         n_step_returns=5, replay_mem_size=20_000, ou_max_sigma=1.0, ou_min_sigma=1.0, random_seed=3)
     core = build_core(cfg, "cuda")
     rp = HbmReplay(cfg, "cuda", core.dev_state)
     env = make_device_env(cfg, 64, "cuda", seed=3)
@@ -273,3 +275,14 @@ def test_rollout_with_terminal_states_equals_the_host_nstep_assembler():
             np.testing.assert_allclose(got[:, e, : 2 * S + A + 3], want[:, : 2 * S + A + 3], rtol=1e-6, atol=1e-7)
         assert (got[:, :, S + A + 1][done] == 1).all()                    # the step that ended an episode is terminal
     assert terminals > 20
+
+
+def test_device_explorers_refuse_a_sigma_schedule():
+    """The host agents anneal the OU sigma (ou_max_sigma -> ou_min_sigma); the noise kernel takes one value, so a
+    configuration that asks for a schedule is refused instead of trained differently."""
+    from d4pg_pytorch_amd.actors.gpu_rollout import DeviceRollout
+    from d4pg_pytorch_amd.actors.rollout_worker import _RowShape
+    from d4pg_pytorch_amd.envs.device_pendulum import DevicePendulum
+    cfg = default_config(env="Pendulum-v0", model="d4pg", dense_size=128, device="cuda", ou_max_sigma=0.3, ou_min_sigma=0.1)
+    with pytest.raises(ValueError, match="constant sigma"):
+        DeviceRollout(cfg, DevicePendulum(16, "cuda", seed=1), _RowShape(3, 1), "cuda", segment=32)
