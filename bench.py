@@ -483,7 +483,19 @@ def main() -> None:
             # nothing the other run does can affect it; `value` is the faster of the two (a job is free to set
             # dp_mode), both are reported with the rule's own pick (`dp_mode_auto`)
             import threading
-            auto = resolve_dp_mode("auto", args.batch, world, args.dtype)
+            # what dp_mode: auto picks on THIS machine: the framework times one all-reduce of the critic's gradient
+            # bucket on the live communicator (parallel/comm.py::probe_allreduce_us) and compares the two modes' costs
+            from d4pg_pytorch_amd.models.nets import NetLayout
+            from d4pg_pytorch_amd.parallel.comm import probe_allreduce_us
+            bucket = NetLayout.build(S + A, cfg["dense_size"], cfg["num_atoms"] if args.model == "d4pg" else 1).numel
+            try:
+                ar_us = probe_allreduce_us(comm, bucket, device)
+                extra["allreduce_probe_us"] = round(ar_us, 2)
+                extra["allreduce_probe_bytes"] = bucket * 4
+            except Exception as exc:
+                ar_us = None
+                extra["allreduce_probe_error"] = repr(exc)[:200]
+            auto = resolve_dp_mode("auto", args.batch, world, args.dtype, allreduce_us=ar_us)
             runners = {"replicated": run_replicated, "grad_allreduce": run_grad_allreduce}
             other = "grad_allreduce" if auto == "replicated" else "replicated"
             # Neither mode has ever met more than one GPU before a job like this one runs, so the first mode is

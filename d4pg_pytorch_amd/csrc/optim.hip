@@ -59,7 +59,8 @@ struct AdamPolyakArgs {
     ShadowArgs sh;
 };
 
-__device__ __forceinline__ void write_shadows(const ShadowArgs& sh, long long e, const f32x4& p, const f32x4* t) {
+// ``t`` is read only where ``has_t``; both by value, so that neither vector is forced into scratch memory for its address
+__device__ __forceinline__ void write_shadows(const ShadowArgs& sh, long long e, const f32x4 p, const f32x4 t, const bool has_t) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         if (j >= sh.count) break;
@@ -77,7 +78,7 @@ __device__ __forceinline__ void write_shadows(const ShadowArgs& sh, long long e,
                     if (m.f_off >= 0) {
                         const long long so = m.f_off + packed16_off(o, i, m.f_ld >> 4);
                         ps[so] = p[k];
-                        if (sh.t_shadow != nullptr && t != nullptr) ((float*)sh.t_shadow)[so] = (*t)[k];
+                        if (sh.t_shadow != nullptr && has_t) ((float*)sh.t_shadow)[so] = t[k];
                     }
                     if (m.b_off >= 0 && i >= m.b_c0 && i < m.b_c1) ps[m.b_off + packed16_off(i - m.b_c0, o, m.b_ld >> 4)] = p[k];
                     continue;
@@ -85,7 +86,7 @@ __device__ __forceinline__ void write_shadows(const ShadowArgs& sh, long long e,
                 if (m.f_off >= 0) {
                     const long long so = m.f_off + packed32_off(o, i, m.f_ld >> 5);
                     ps[so] = p[k];
-                    if (sh.t_shadow != nullptr && t != nullptr) ((float*)sh.t_shadow)[so] = (*t)[k];
+                    if (sh.t_shadow != nullptr && has_t) ((float*)sh.t_shadow)[so] = t[k];
                 }
                 if (m.b_off >= 0 && i >= m.b_c0 && i < m.b_c1) ps[m.b_off + packed32_off(i - m.b_c0, o, m.b_ld >> 5)] = p[k];
                 continue;
@@ -94,7 +95,7 @@ __device__ __forceinline__ void write_shadows(const ShadowArgs& sh, long long e,
             if (m.f_off >= 0) {
                 const long long so = m.f_off + packed_off(o, i, m.f_ld >> 5);
                 ps[so] = (__bf16)p[k];
-                if (sh.t_shadow != nullptr && t != nullptr) ((__bf16*)sh.t_shadow)[so] = (__bf16)(*t)[k];
+                if (sh.t_shadow != nullptr && has_t) ((__bf16*)sh.t_shadow)[so] = (__bf16)t[k];
             }
             if (m.b_off >= 0 && i >= m.b_c0 && i < m.b_c1)
                 ps[m.b_off + packed_off(i - m.b_c0, o, m.b_ld >> 5)] = (__bf16)p[k];
@@ -125,14 +126,14 @@ __global__ __launch_bounds__(256) void adam_polyak_kernel(const AdamPolyakArgs a
         reinterpret_cast<f32x4*>(a.p)[i] = p;
         reinterpret_cast<f32x4*>(a.m)[i] = m;
         reinterpret_cast<f32x4*>(a.v)[i] = v;
-        f32x4 t;
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
         if (a.t != nullptr) {
             t = reinterpret_cast<f32x4*>(a.t)[i];
 #pragma unroll
             for (int k = 0; k < 4; ++k) t[k] = (1.f - a.tau) * t[k] + a.tau * p[k];
             reinterpret_cast<f32x4*>(a.t)[i] = t;
         }
-        if (a.sh.count > 0) write_shadows(a.sh, i * 4, p, a.t != nullptr ? &t : nullptr);
+        if (a.sh.count > 0) write_shadows(a.sh, i * 4, p, t, a.t != nullptr);
     }
     // step_done is read only by the first kernel of the next update
     if (a.finish_step && blockIdx.x == 0) {

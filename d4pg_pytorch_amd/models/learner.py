@@ -260,8 +260,20 @@ class Learner:
         self.log_dir = log_dir
         self.num_train_steps = int(config["num_steps_train"])
         # replicated data parallelism: every rank runs the update on the global batch
+        probe_us = None
+        if self.comm.world > 1 and config.get("dp_mode", "auto") == "auto" and self.device.type == "cuda":
+            # what an all-reduce of the critic's gradient bucket costs on THIS machine's communicator
+            from ..parallel.comm import probe_allreduce_us
+            from .nets import NetLayout
+            bucket = NetLayout.build(int(config["state_dim"]) + int(config["action_dim"]), int(config["dense_size"]),
+                                     int(config["num_atoms"]) if config["model"] == "d4pg" else 1).numel
+            probe_us = probe_allreduce_us(self.comm, bucket, self.device)
+            if rank == 0:
+                print(f"[learner] all-reduce of a {bucket * 4 >> 10} KiB gradient bucket over {self.comm.world} ranks: "
+                      f"{probe_us:.1f} us", flush=True)
         dp_mode = resolve_dp_mode(config.get("dp_mode", "auto"), int(config["batch_size"]), self.comm.world,
-                                  str(config.get("compute_dtype", "auto")))
+                                  str(config.get("compute_dtype", "auto")), allreduce_us=probe_us)
+        self.dp_mode, self.allreduce_probe_us = dp_mode, probe_us
         self.replicated = (self.comm.world > 1 and dp_mode == "replicated"
                            and self.device.type == "cuda" and config.get("fused_learner", "auto") != "torch")
         core_cfg = dict(config, batch_size=int(config["batch_size"]) * self.comm.world) if self.replicated else config

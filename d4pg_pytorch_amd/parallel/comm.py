@@ -176,22 +176,70 @@ class TorchDistComm(Comm):
             self._owns = False
 
 
-#: Largest global batch for which ``dp_mode: auto`` replicates the update, by compute precision.  Measured on
-#: one MI355X, us per update on the global batch (what every rank of the replicated mode pays, plus the
-#: all-gather): fp32 256: 78, 512: 86, 1024: 105, 2048: 143, 4096: 258; bf16 256: 52, 2048: 64, 4096: 89, 8192: 131.
-#: The gradient-exchange mode over a world of ONE (two all-reduces as nodes of the update graph, stand-alone
-#: optimiser kernels) costs 94 us (fp32) / 68 us (bf16) at 256 rows per rank before any xGMI latency of the two
-#: 0.7-0.9 MB all-reduces, i.e. an estimated 150-170 / 125-145 us on eight GPUs: redoing the other ranks' rows
-#: is cheaper than that up to 2048 (fp32) / 8192 (bf16) rows.
+#: One GPU, us per update by batch size (Walker2d shape, ``profiles/README.md``): what a rank of the replicated mode pays
+#: for the GLOBAL batch, and a rank of the gradient-exchange mode for its LOCAL batch.
+UPDATE_US = {"fp32": {256: 78.0, 512: 86.0, 1024: 106.0, 2048: 145.0, 4096: 221.0},
+             "bf16": {256: 52.0, 512: 55.0, 1024: 59.0, 2048: 64.0, 4096: 90.0, 8192: 131.0}}
+#: what the gradient-exchange mode costs on top of the update and its two all-reduces (stand-alone optimiser kernels,
+#: gradients through memory): measured over a world of one, 94.7 - 77.8 us (fp32), 68.7 - 52.2 us (bf16)
+EXCHANGE_OVERHEAD_US = {"fp32": 17.0, "bf16": 16.5}
+#: Without a live communicator to time (``resolve_dp_mode`` called with ``allreduce_us=None``): the largest global batch that is
+#: replicated, by precision; an all-reduce of a 0.8 MB gradient bucket is then taken to cost 35 us.
 REPLICATED_MAX_GLOBAL_BATCH = {"fp32": 2048, "bf16": 8192}
 
 
-def resolve_dp_mode(mode: str, local_batch: int, world: int, compute_dtype: str = "fp32") -> str:
-    """``auto`` -> ``replicated`` while the global batch is small enough, else ``grad_allreduce``."""
+def update_us(batch: int, compute_dtype: str = "fp32") -> float:
+    """Interpolated single-GPU update time at ``batch`` rows (linear between the measured sizes, linear in the batch
+    beyond the largest)."""
+    tab = UPDATE_US["bf16" if compute_dtype == "bf16" else "fp32"]
+    xs = sorted(tab)
+    if batch <= xs[0]:
+        return tab[xs[0]]
+    for lo, hi in zip(xs, xs[1:]):
+        if batch <= hi:
+            return tab[lo] + (tab[hi] - tab[lo]) * (batch - lo) / (hi - lo)
+    return tab[xs[-1]] * batch / xs[-1]
+
+
+def probe_allreduce_us(comm: "Comm", numel: int, device, iters: int = 20) -> float:
+    """Time of one sum all-reduce of ``numel`` floats on the LIVE communicator (median of ``iters`` after a warm-up,
+    then the maximum over the ranks, so that every rank decides from the same number).  This is what replaces a
+    guessed xGMI latency in ``dp_mode: auto``."""
+    import time
+    buf = torch.zeros(int(numel), dtype=torch.float32, device=device)
+    cuda = torch.device(device).type == "cuda"
+    for _ in range(3):
+        comm.all_reduce_sum_(buf)
+    if cuda:
+        torch.cuda.synchronize(device)
+    times = []
+    for _ in range(iters):
+        comm.barrier()
+        t0 = time.perf_counter()
+        comm.all_reduce_sum_(buf)
+        if cuda:
+            torch.cuda.synchronize(device)
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    return comm.all_reduce_max_scalar(times[len(times) // 2] * 1e6)
+
+
+def resolve_dp_mode(mode: str, local_batch: int, world: int, compute_dtype: str = "fp32",
+                    allreduce_us: Optional[float] = None) -> str:
+    """``auto`` -> the cheaper of the two modes per update.  ``replicated`` pays the single-GPU update time of the
+    GLOBAL batch; ``grad_allreduce`` that of the local batch, two all-reduces of a gradient bucket on the critical
+    path (``allreduce_us`` each: measured on the live communicator by :func:`probe_allreduce_us` at attach time) and
+    the stand-alone optimiser kernels.  Without a measurement the static limits of ``REPLICATED_MAX_GLOBAL_BATCH``."""
     if mode != "auto":
         return mode
-    limit = REPLICATED_MAX_GLOBAL_BATCH["bf16" if compute_dtype == "bf16" else "fp32"]
-    return "replicated" if int(local_batch) * int(world) <= limit else "grad_allreduce"
+    if world <= 1:
+        return "replicated"
+    dt = "bf16" if compute_dtype == "bf16" else "fp32"
+    if allreduce_us is None:
+        return "replicated" if int(local_batch) * int(world) <= REPLICATED_MAX_GLOBAL_BATCH[dt] else "grad_allreduce"
+    replicated = update_us(int(local_batch) * int(world), dt)
+    exchange = update_us(int(local_batch), dt) + 2.0 * float(allreduce_us) + EXCHANGE_OVERHEAD_US[dt]
+    return "replicated" if replicated <= exchange else "grad_allreduce"
 
 
 def attach_data_parallel(core, comm: Comm) -> None:

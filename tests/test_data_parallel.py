@@ -112,6 +112,45 @@ def test_dp_mode_auto_replicates_only_small_global_batches():
     assert resolve_dp_mode("auto", 1024, 8, "bf16") == "replicated"
     assert resolve_dp_mode("auto", 4096, 8, "bf16") == "grad_allreduce"
     assert resolve_dp_mode("auto", 4096, 8) == "grad_allreduce"
-    assert resolve_dp_mode("auto", 16384, 1) == "grad_allreduce"     # irrelevant for one rank, but well defined
+    assert resolve_dp_mode("auto", 16384, 1) == "replicated"         # one rank has nobody to exchange with
     assert resolve_dp_mode("grad_allreduce", 256, 2) == "grad_allreduce"
     assert resolve_dp_mode("replicated", 4096, 8) == "replicated"
+
+
+def test_dp_mode_auto_follows_the_measured_all_reduce_time():
+    """With a probe the choice is a cost comparison: update(global batch) against update(local batch) + two all-reduces
+    + the stand-alone optimiser kernels."""
+    from d4pg_pytorch_amd.parallel.comm import EXCHANGE_OVERHEAD_US, resolve_dp_mode, update_us
+    assert update_us(256) == 78.0 and update_us(128) == 78.0
+    assert update_us(768) == pytest.approx((86.0 + 106.0) / 2)
+    assert update_us(8192) == pytest.approx(2 * 221.0)                     # linear in the batch past the table
+    # headline shape, 8 ranks x 256 rows: replicated 2048 rows = 145 us; exchange = 78 + 17 + 2 t
+    assert resolve_dp_mode("auto", 256, 8, "fp32", allreduce_us=20.0) == "grad_allreduce"      # 135 < 145
+    assert resolve_dp_mode("auto", 256, 8, "fp32", allreduce_us=30.0) == "replicated"          # 155 > 145
+    # a slow fabric (gloo over loopback: milliseconds) replicates even batches the static limit would exchange
+    assert resolve_dp_mode("auto", 4096, 8, "fp32") == "grad_allreduce"
+    assert resolve_dp_mode("auto", 4096, 8, "fp32", allreduce_us=5000.0) == "replicated"
+    # and a fast one exchanges where the static limit would replicate
+    assert resolve_dp_mode("auto", 1024, 2, "fp32") == "replicated"
+    assert resolve_dp_mode("auto", 1024, 2, "fp32", allreduce_us=5.0) == "grad_allreduce"      # 106+17+10 < 145
+    t_break = (update_us(2048, "bf16") - update_us(256, "bf16") - EXCHANGE_OVERHEAD_US["bf16"]) / 2
+    assert t_break < 0       # bf16 at 8 x 256: no all-reduce is fast enough, the update itself is too cheap
+    assert resolve_dp_mode("auto", 256, 8, "bf16", allreduce_us=0.0) == "replicated"
+    assert resolve_dp_mode("grad_allreduce", 256, 8, "bf16", allreduce_us=1e9) == "grad_allreduce"
+
+
+def test_probe_times_the_live_communicator_and_agrees_across_ranks():
+    import threading
+    from d4pg_pytorch_amd.parallel.comm import LocalComm, probe_allreduce_us
+    from d4pg_pytorch_amd.parallel.fake_comm import ThreadComm
+    assert probe_allreduce_us(LocalComm(), 1000, "cpu", iters=3) >= 0.0
+    comms, out = ThreadComm.group(4), [None] * 4
+
+    def run(r):
+        out[r] = probe_allreduce_us(comms[r], 50_000, "cpu", iters=5)
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(4)]
+    [t.start() for t in ts]
+    [t.join(60) for t in ts]
+    assert all(o is not None and o > 0 for o in out), out
+    assert len(set(out)) == 1, out          # the maximum over the ranks: every rank decides from the same number

@@ -42,12 +42,13 @@ def _rows_of(b, lo, hi):
                  b.gamma[lo:hi], b.weights[lo:hi], b.indices[lo:hi])
 
 
-@pytest.mark.parametrize("dtype,model", [("fp32", "d4pg"), ("fp32", "d3pg"), ("bf16", "d4pg")])
-def test_two_thread_ranks_grad_allreduce_equal_one_learner_on_the_concatenated_batch(dtype, model):
+@pytest.mark.parametrize("dtype,model,world", [("fp32", "d4pg", 2), ("fp32", "d3pg", 2), ("bf16", "d4pg", 2),
+                                               ("fp32", "d4pg", 4), ("bf16", "d4pg", 4)])
+def test_thread_ranks_grad_allreduce_equal_one_learner_on_the_concatenated_batch(dtype, model, world):
     from d4pg_pytorch_amd.models.core import build_core
     from d4pg_pytorch_amd.parallel.comm import attach_data_parallel
     from d4pg_pytorch_amd.parallel.fake_comm import ThreadComm
-    world, Bl, steps = 2, 128, 5
+    Bl, steps = 128 if world == 2 else 64, 5
     cfg_l, cfg_g = _cfg(Bl, dtype, model=model), _cfg(Bl * world, dtype, model=model)
     batches = [_batch(cfg_g, Bl * world, 50 + i) for i in range(steps)]
     comms = ThreadComm.group(world)
@@ -72,8 +73,9 @@ def test_two_thread_ranks_grad_allreduce_equal_one_learner_on_the_concatenated_b
     [t.join(180) for t in ts]
     assert not errs, errs
     # both ranks applied the same summed gradients to the same parameters
-    assert torch.equal(cores[0].online.flat, cores[1].online.flat)
-    assert torch.equal(cores[0].target.flat, cores[1].target.flat)
+    for r in range(1, world):
+        assert torch.equal(cores[0].online.flat, cores[r].online.flat)
+        assert torch.equal(cores[0].target.flat, cores[r].target.flat)
     single = build_core(cfg_g, "cuda", seed=100)
     for b in batches:
         p_single = single.update(b).clone()

@@ -183,3 +183,49 @@ def test_f32_drawn_ahead_chunks_equal_one_update_at_a_time():
     p1, t1 = run(1)
     p8, t8 = run(16)
     assert torch.equal(p1, p8) and torch.equal(t1, t8)
+
+
+def test_f32_ride_along_prioritised_draw_is_proportional():
+    """Prioritised replay on the fused fp32 core: the batch of update k + 1 is drawn INSIDE update k (workgroups of the
+    actor-phase launch, behind the priority write-back in the weight-gradient launch before it).  Distribution and
+    importance weights of those draws against the tree they were made from: P(i) = p_i / sum p, w_i = (p_min / p_i)^beta
+    (``models/d4pg/replay_buffer.py:129-137,177-185``), over 240 updates."""
+    from d4pg_pytorch_amd.models.core import build_core
+    from d4pg_pytorch_amd.replay.hbm_replay import HbmReplay
+    cfg = _cfg("d4pg", replay_mem_size=5000, replay_memory_prioritized=1, priority_beta_start=0.5, priority_beta_end=0.5,
+               sample_ahead=1)
+    core = build_core(cfg, "cuda")
+    rp = HbmReplay(cfg, "cuda", core.dev_state)
+    core.attach_replay(rp)
+    assert core._per_ahead(), "the configuration must take the ride-along draw (CriticAhead mode 3)"
+    n = 3000
+    g = torch.Generator().manual_seed(4)
+    rows = torch.randn(n, rp.row_ld, generator=g)
+    rows[:, rp.S + rp.A + 1] = (torch.rand(n, generator=g) < 0.05).float()
+    rows[:, rp.S + rp.A + 2] = 0.99 ** 5
+    rp.insert(rows.cuda())
+    rp.update_priorities(torch.arange(n), torch.rand(n, generator=g) * 5 + 0.01)      # a spread of priorities to start from
+    B, T = cfg["batch_size"], 240
+    counts = torch.zeros(n, dtype=torch.float64)
+    expected = torch.zeros(n, dtype=torch.float64)
+    for k in range(T):
+        core.update_from_replay()
+        torch.cuda.synchronize()
+        leaf = rp.leaf[:n].cpu().double()          # the tree after this update's write-back: what its draw saw
+        ii = core.idx.cpu()
+        assert ii.min() >= 0 and ii.max() < n
+        counts += torch.bincount(ii, minlength=n).double()
+        expected += B * leaf / leaf.sum()
+        if k % 60 == 0:
+            want_w = (leaf.min() / leaf[ii]) ** 0.5
+            torch.testing.assert_close(core.weights.cpu().double(), want_w, rtol=2e-4, atol=1e-6)
+    assert counts.sum() == T * B
+    # pooled by expected mass into 30 bins; stratified draws have less variance than multinomial ones
+    order = torch.argsort(expected)
+    chi2 = sum(((counts[b].sum() - expected[b].sum()) ** 2 / expected[b].sum()).item() for b in torch.chunk(order, 30))
+    assert chi2 < 80, chi2
+    # and row by row: nothing is drawn that has (almost) no mass, heavy rows are drawn about as often as expected
+    heavy = expected > 40
+    assert heavy.sum() > 50
+    ratio = counts[heavy] / expected[heavy]
+    assert 0.6 < ratio.min() and ratio.max() < 1.5 and abs(ratio.mean() - 1.0) < 0.05, (ratio.min(), ratio.max(), ratio.mean())
