@@ -206,6 +206,8 @@ def test_f32_ride_along_prioritised_draw_is_proportional():
     rp.insert(rows.cuda())
     rp.update_priorities(torch.arange(n), torch.rand(n, generator=g) * 5 + 0.01)      # a spread of priorities to start from
     B, T = cfg["batch_size"], 240
+    torch.cuda.synchronize()
+    leaf0 = rp.leaf[:n].cpu().double()
     counts = torch.zeros(n, dtype=torch.float64)
     expected = torch.zeros(n, dtype=torch.float64)
     for k in range(T):
@@ -220,12 +222,16 @@ def test_f32_ride_along_prioritised_draw_is_proportional():
             want_w = (leaf.min() / leaf[ii]) ** 0.5
             torch.testing.assert_close(core.weights.cpu().double(), want_w, rtol=2e-4, atol=1e-6)
     assert counts.sum() == T * B
-    # pooled by expected mass into 30 bins; stratified draws have less variance than multinomial ones
-    order = torch.argsort(expected)
+    # Each draw has conditional mean B p_i / sum p given the tree it was made from, so counts - expected is a
+    # martingale for every row and for every set of rows FIXED IN ADVANCE (sets chosen by the final priorities are
+    # not: a row drawn early by chance has a small priority ever after).  30 bins by the starting priorities;
+    # stratified draws have less variance than multinomial ones.
+    order = torch.argsort(leaf0)
     chi2 = sum(((counts[b].sum() - expected[b].sum()) ** 2 / expected[b].sum()).item() for b in torch.chunk(order, 30))
     assert chi2 < 80, chi2
-    # and row by row: nothing is drawn that has (almost) no mass, heavy rows are drawn about as often as expected
-    heavy = expected > 40
-    assert heavy.sum() > 50
-    ratio = counts[heavy] / expected[heavy]
-    assert 0.6 < ratio.min() and ratio.max() < 1.5 and abs(ratio.mean() - 1.0) < 0.05, (ratio.min(), ratio.max(), ratio.mean())
+    # and row by row: nothing far from its expectation, no drift of the mean
+    seen = expected > 20
+    assert seen.sum() > 500
+    z = (counts[seen] - expected[seen]) / expected[seen].sqrt()
+    assert z.abs().max() < 6.0, z.abs().max()
+    assert abs((counts[seen].sum() / expected[seen].sum()).item() - 1.0) < 0.02
