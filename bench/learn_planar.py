@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--v-min", type=float, default=None)
     ap.add_argument("--v-max", type=float, default=None)
     ap.add_argument("--out", default="gpurun_out/planar")
+    ap.add_argument("--overlap", action="store_true", help="collect the next segment beside the updates (the learner's own loop)")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     with open(os.path.join(args.out, "runs.jsonl"), "a") as fh:
@@ -46,7 +47,8 @@ def main():
             for seed in range(args.seeds):
                 r = train_on_device(args.model, args.core, args.updates, seed=300 + seed, envs=args.envs,
                                              segment=args.segment, eval_every=args.eval_every, env=env, max_ep_length=limit,
-                                             tau=args.tau, v_min=v_min, v_max=v_max)
+                                             tau=args.tau, v_min=v_min, v_max=v_max, overlap=args.overlap)
+                r["overlap"] = bool(args.overlap)
                 r["envs"], r["env_steps_per_update"] = args.envs, args.envs * args.segment / 32
                 r["env_steps_per_s"] = round(r["env_steps"] / r["wall_s"], 0)
                 r["updates_per_s"] = round(r["updates"] / r["wall_s"], 1)

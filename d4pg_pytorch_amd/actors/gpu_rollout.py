@@ -5,9 +5,13 @@ The reference's explorers are CPU processes that push one pickled transition per
 pipe (``models/agent.py:51-154``).  For environments that exist as device kernels (``envs/device_pendulum.py``)
 the whole loop runs on the GPU instead: a *segment* of ``T`` steps of ``E`` environments is
 
-    T x [ actor_infer32 (one launch, online actor) -> OU noise (Philox) -> environment step ]
+    T x [ actor_infer32 (online actor; OU noise and the clip in its last epilogue) -> environment step ]
     -> n-step targets of the [T, E] segment (``csrc/nstep.hip``)
     -> replay rows (``rollout_rows_kernel``)
+
+i.e. TWO launches per environment step: the Philox position of the noise is the environment's step counter, which the
+environment's kernel advances itself (``envs/device_pendulum.py::StepCounter``).  ``fuse_noise=False`` keeps noise
+and counter in launches of their own (four per step), for the test that both orders of work produce the same rows.
 
 captured once as a HIP graph and replayed; the rows then enter the HBM replay with one ``replay_insert``
 launch on the learner's stream.  The learner's update occupies a fraction of the 256 CUs, so the segment
@@ -29,7 +33,7 @@ from .gpu_actor import PackedActor32
 
 class DeviceRollout:
     def __init__(self, cfg: Dict, env, replay, device="cuda", segment: int = 32, seed: int = 0,
-                 explore: bool = True, use_graph: bool = True):
+                 explore: bool = True, use_graph: bool = True, fuse_noise: bool = True):
         self.cfg, self.env, self.replay = cfg, env, replay
         self.device = torch.device(device)
         self.E, self.T = env.E, int(segment)
@@ -65,6 +69,12 @@ class DeviceRollout:
         self.ou_x = z(E, self.lda)
         self.ou_counter = z(1, dt=torch.int64)
         env.noise = self.ou_x              # a new episode starts from zero noise (utils/utils.py:21-22 reset())
+        self.fuse_noise = bool(fuse_noise) and hasattr(getattr(env, "counter", None), "paired")
+        if self.fuse_noise:
+            env.counter.paired = True      # the environment's kernel advances the counter: no launch for it
+        #: kernel nodes of the captured segment graph: T x (policy, [noise,] environment [, counter]) + n-step targets
+        #: + rows (the first observations move in a copy node)
+        self.graph_kernels = 0
         self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         self.stream = torch.cuda.Stream(device=self.device)
         self.done_event = torch.cuda.Event()
@@ -95,20 +105,36 @@ class DeviceRollout:
         # environment's kernel once per step; different stream constants and seeds keep the two draws apart)
         shared = getattr(self.env, "counter", None)
         a.sigma, a.seed = None, self.seed
-        a.counter = (shared if shared is not None else self.ou_counter).data_ptr()
+        a.counter = shared.ptr if shared is not None else self.ou_counter.data_ptr()
         a.n, a.A = self.E * self.lda, self.lda
         a.theta, a.mu = float(cfg["ou_theta"]), float(cfg["ou_mu"])
         a.sigma_const = float(cfg["ou_max_sigma"]) if self.explore else 0.0
         a.low, a.high = float(cfg["action_low"]), float(cfg["action_high"])
         H.launch("d4pg_ou_noise_shared_counter" if shared is not None else "d4pg_ou_noise", a)
 
+    def _infer_with_noise(self, t: int) -> None:
+        cfg = self.cfg
+        a = self.actor.infer_args(self.obs[t], self.act[t], self.E, self.action_scale)
+        a.ou.x, a.ou.counter, a.ou.seed = self.ou_x.data_ptr(), self.env.counter.ptr, self.seed
+        a.ou.theta, a.ou.mu = float(cfg["ou_theta"]), float(cfg["ou_mu"])
+        a.ou.sigma = float(cfg["ou_max_sigma"]) if self.explore else 0.0
+        a.ou.low, a.ou.high = float(cfg["action_low"]), float(cfg["action_high"])
+        self.actor.infer(a, self.E)
+
     def _enqueue_segment(self) -> None:
         T, E = self.T, self.E
         self.obs[0].copy_(self.obs[T])
+        if self.fuse_noise:
+            self.env.counter.rewind()          # nothing in steady state: every segment ends on the slot it started from
         for t in range(T):
-            self.actor.infer(self.actor.infer_args(self.obs[t], self.act_raw, E, self.action_scale), E)
-            self._ou(t)
+            if self.fuse_noise:
+                self._infer_with_noise(t)
+            else:
+                self.actor.infer(self.actor.infer_args(self.obs[t], self.act_raw, E, self.action_scale), E)
+                self._ou(t)
             self.env.step(self.act[t], self.obs[t + 1], self.next_obs[t], self.reward[t], self.done[t], self.trunc[t])
+        if self.fuse_noise:
+            self.env.counter.rewind()          # one tiny launch per SEGMENT if T is odd
         na = H.NstepArgs()
         na.reward, na.done, na.trunc = self.reward.data_ptr(), self.done.data_ptr(), self.trunc.data_ptr()
         na.R, na.gk, na.nxt, na.d = self.R.data_ptr(), self.gk.data_ptr(), self.nxt.data_ptr(), self.d.data_ptr()
@@ -130,9 +156,11 @@ class DeviceRollout:
         was = gc.isenabled()
         gc.disable()                                # a collected tensor would be freed during capture
         try:
-            g = torch.cuda.CUDAGraph()
+            g = torch.cuda.CUDAGraph(keep_graph=True)
             with torch.cuda.graph(g, stream=self.stream, capture_error_mode="thread_local"):
                 self._enqueue_segment()
+            self.graph_kernels = H.graph_kernel_nodes(g)
+            g.instantiate()
             self._graph = g
         finally:
             if was:
@@ -188,6 +216,12 @@ class DeviceRollout:
         n = self.drain()
         self.launch(flat_ptr, actor_base)
         return n
+
+    @property
+    def launches_per_step(self) -> float:
+        """Kernel launches per environment step of a replayed segment, the per-segment launches (n-step targets, rows,
+        a counter rewind after an odd number of steps) spread over its steps."""
+        return self.graph_kernels / self.T
 
     def episode_stats(self) -> Tuple[Optional[float], int]:
         return self.env.episode_stats()

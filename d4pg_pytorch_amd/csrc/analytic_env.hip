@@ -16,6 +16,7 @@ struct AnalyticEnvArgs {
     float* noise;            // [E][ld_act] exploration-noise state, zeroed where an episode ends; or null
     double* stats;           // [2] sum of finished episode returns, number of finished episodes
     unsigned long long* counter;
+    unsigned long long* counter_next;   // null: a follow-up launch increments `counter` in place; else this launch leaves counter + 1 here
     unsigned long long seed;
     int E, ld_act, time_limit, init;
     int limit_terminal, kind;        // kind: 0 Reacher, 1 InvertedDoublePendulum
@@ -113,6 +114,7 @@ template <int KIND>
 __global__ __launch_bounds__(256) void analytic_step_kernel(const AnalyticEnvArgs a) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned long long ctr = *a.counter;
+    next_counter(a.counter_next, ctr);
     if (e >= a.E) return;
     float* st = a.state + (size_t)e * 8;
     float s[6];
@@ -192,7 +194,7 @@ D4PG_API int d4pg_analytic_env_step(const AnalyticEnvArgs* a, hipStream_t stream
     const dim3 grid((a->E + 255) / 256), block(256);
     if (a->kind == 0) hipLaunchKernelGGL(analytic::analytic_step_kernel<0>, grid, block, 0, stream, *a);
     else hipLaunchKernelGGL(analytic::analytic_step_kernel<1>, grid, block, 0, stream, *a);
-    hipLaunchKernelGGL(analytic::counter_kernel, dim3(1), dim3(64), 0, stream, a->counter);
+    if (a->counter_next == nullptr) hipLaunchKernelGGL(analytic::counter_kernel, dim3(1), dim3(64), 0, stream, a->counter);
     return (int)hipGetLastError();
 }
 D4PG_SIZEOF(AnalyticEnvArgs)

@@ -18,6 +18,7 @@ struct AntEnvArgs {
     float* noise;            // [E][ld_act] exploration-noise state, zeroed where an episode ends; or null
     double* stats;           // [2] sum of finished episode returns, number of finished episodes
     unsigned long long* counter;
+    unsigned long long* counter_next;   // null: a follow-up launch increments `counter` in place; else this launch leaves counter + 1 here
     unsigned long long seed;
     int E, ld_act, time_limit, init;
     int limit_terminal;
@@ -30,6 +31,7 @@ __device__ __forceinline__ float unit(uint32_t r) { return (float)(r >> 8) * (1.
 __global__ __launch_bounds__(64) void ant_step_kernel(const AntEnvArgs a) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned long long ctr = *a.counter;
+    next_counter(a.counter_next, ctr);
     if (e >= a.E) return;
     const AntParams* P = a.P;      // (not restrict-qualified: csrc/ant_sim.h)
     float* st = a.state + (size_t)e * STRIDE;
@@ -133,7 +135,7 @@ D4PG_API int d4pg_ant_env_step(const AntEnvArgs* a, const AntParams* host_params
         if (host_params->c_link[c] != ant::contact_link(c)) return -3;
     if (host_params->substeps < 1 || host_params->substeps > 64 || !(host_params->dt > 0.f)) return -4;
     hipLaunchKernelGGL(ant::ant_step_kernel, dim3((a->E + 63) / 64), dim3(64), 0, stream, *a);
-    hipLaunchKernelGGL(ant::counter_kernel, dim3(1), dim3(64), 0, stream, a->counter);
+    if (a->counter_next == nullptr) hipLaunchKernelGGL(ant::counter_kernel, dim3(1), dim3(64), 0, stream, a->counter);
     return (int)hipGetLastError();
 }
 D4PG_SIZEOF(AntParams)

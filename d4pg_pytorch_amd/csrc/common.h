@@ -107,6 +107,13 @@ __device__ __forceinline__ float wave_min(float v) {
 }
 
 // Philox-4x32-10 counter-based generator (one call = 4 x 32 random bits).
+// The step counter of a device environment (the Philox stream position of its resets and of the exploration noise) can
+// be a PAIR of slots: a step reads one and one thread leaves counter + 1 in the other, which the kernels of the next
+// step read.  No launch of its own, and no kernel reads a slot that a kernel of the same step writes.
+__device__ __forceinline__ void next_counter(unsigned long long* next, unsigned long long ctr) {
+    if (next != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *next = ctr + 1ull;
+}
+
 __device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                            uint32_t k0, uint32_t k1, uint32_t out[4]) {
 #pragma unroll
@@ -121,6 +128,24 @@ __device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// One Ornstein-Uhlenbeck step of element i at stream position ctr (utils/utils.py:24-28 of the reference):
+// x <- x + theta (mu - x) + sigma N(0, 1), N from Philox-4x32 + Box-Muller.  Shared by the stand-alone noise kernel
+// (csrc/nstep.hip) and the policy kernel's epilogue (csrc/fused32.hip); contraction is off so that both round alike.
+__device__ __forceinline__ float ou_advance(float x, uint32_t i, unsigned long long ctr, unsigned long long seed,
+                                            float theta, float mu, float sigma) {
+#pragma clang fp contract(off)
+    uint32_t r[4];
+    philox4x32(i, (uint32_t)ctr, (uint32_t)(ctr >> 32), 0x0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    const float u1 = fmaxf((float)(r[0] >> 8) * (1.0f / 16777216.0f), 1e-7f);
+    const float u2 = (float)(r[1] >> 8) * (1.0f / 16777216.0f);
+    const float nrm = sqrtf(-2.f * logf(u1)) * cosf(6.2831853f * u2);
+    return x + theta * (mu - x) + sigma * nrm;
+}
+__device__ __forceinline__ float ou_apply(float action, float x, float low, float high) {
+#pragma clang fp contract(off)
+    return fminf(high, fmaxf(low, action + x));
 }
 
 // uniform double in [0,1) from 53 random bits

@@ -845,6 +845,17 @@ __global__ __launch_bounds__(64 * NW32) void actor_phase32_kernel(const ActorPha
 // copy per step and environment): the three actor layers on a tile of 4 * MT environments per workgroup,
 // weights from packed fp32 copies (csrc/mlp32_dev.h), activations in LDS.  Used by GPU exploiters /
 // explorers (actors/gpu_actor.py) and by the device-resident rollout (actors/gpu_rollout.py).
+// Exploration noise in the policy's last epilogue (utils/utils.py:9-34 of the reference: Ornstein-Uhlenbeck state per
+// action dimension, x <- x + theta (mu - x) + sigma N(0, 1), action = clip(policy + x)).  The draw is the one of
+// ou_noise_kernel (csrc/nstep.hip): Philox-4x32 at (element index, counter), Box-Muller; so a rollout step is the
+// policy launch and the environment launch, nothing in between.
+struct OuFuse32 {
+    float* x;                             // [E][ld_act] noise state, updated in place; null: no noise, `act` gets the policy's output
+    const unsigned long long* counter;    // Philox stream position of this step (the environment's step counter)
+    unsigned long long seed;
+    float theta, mu, sigma, low, high;
+    int pad_;
+};
 struct ActorInferArgs32 {
     LayerW32 l[3];
     const float* obs;     // [E][ld_obs], first S columns are the observation
@@ -853,6 +864,7 @@ struct ActorInferArgs32 {
     int ld_obs, ld_act, ldx, ldh;
     float action_scale;
     int pad_;
+    OuFuse32 ou;
 };
 
 template <int MT, int KSH, int KSN>
@@ -891,10 +903,23 @@ __global__ __launch_bounds__(64 * NW32) void actor_infer32_kernel(const ActorInf
         put_lds4(bufB, ldh, r0, col, v);
     }, [&] { ch.template prefetch_s<0>(a.l[2]); });
     __syncthreads();
+    const OuFuse32 ou = a.ou;
+    const int A = a.A;
+    const unsigned long long ctr = ou.x != nullptr ? *ou.counter : 0ull;
     ch.template split<0>(bufB, ldh, a.l[2], [=](int r0, int col, f32x4 v) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (row0 + r0 + r < E) act[(size_t)(row0 + r0 + r) * ld_act + col] = fast_tanh(v[r]) * scale;
+        for (int r = 0; r < 4; ++r) {
+            const int row = row0 + r0 + r;
+            if (row >= E) continue;
+            float y = fast_tanh(v[r]) * scale;
+            if (ou.x != nullptr && col < A) {
+                const size_t i = (size_t)row * ld_act + col;
+                const float x = ou_advance(ou.x[i], (uint32_t)i, ctr, ou.seed, ou.theta, ou.mu, ou.sigma);
+                ou.x[i] = x;
+                y = ou_apply(y, x, ou.low, ou.high);
+            }
+            act[(size_t)row * ld_act + col] = y;
+        }
     }, [] {});
 }
 
@@ -1075,6 +1100,7 @@ D4PG_API int d4pg_actor_infer32(const ActorInferArgs32* a, int mt, hipStream_t s
     if (mt != 1 && mt != 2 && mt != 4) return -9;
     if (a->E < 1 || a->S < 1 || a->A < 1 || a->A > 64 || a->obs == nullptr || a->act == nullptr) return -1;
     if ((a->ldx & 3) || (a->ldh & 3) || a->ldx < a->S || a->ld_obs < a->S || a->ld_act < a->A) return -3;
+    if (a->ou.x != nullptr && a->ou.counter == nullptr) return -4;
     const int M = 4 * mt;
     const int ksh = (a->H + 31) / 32;
     const int ksn = a->l[0].nch <= 2 ? 2 : 4;
@@ -1174,6 +1200,7 @@ D4PG_API int d4pg_actor_infer32w(const ActorInferArgs32* a, int mt, hipStream_t 
     if (mt != 2 && mt != 4) return -9;
     if (a->E < 1 || a->S < 1 || a->A < 1 || a->A > 64 || a->obs == nullptr || a->act == nullptr) return -1;
     if ((a->ldx & 3) || (a->ldh & 3) || a->ldx < a->S || a->ld_obs < a->S || a->ld_act < a->A) return -3;
+    if (a->ou.x != nullptr && a->ou.counter == nullptr) return -4;
     const int M = 4 * mt;
     if (int rc = check_layer16(a->l[0], a->ldx)) return rc;
     if (int rc = check_layer16(a->l[1], a->ldh)) return rc;
@@ -1431,4 +1458,5 @@ D4PG_SIZEOF(ActorPhaseArgs32)
 D4PG_SIZEOF(WgradDesc32)
 D4PG_SIZEOF(WgradGroup32)
 D4PG_SIZEOF(ActorInferArgs32)
+D4PG_SIZEOF(OuFuse32)
 #endif   // D4PG_MAIN_UNIT

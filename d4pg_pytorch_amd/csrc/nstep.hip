@@ -75,16 +75,10 @@ __global__ __launch_bounds__(256) void ou_noise_kernel(const OuArgs a) {
     const unsigned long long ctr = *a.counter;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < a.n) {
-        uint32_t r[4];
-        philox4x32((uint32_t)i, (uint32_t)ctr, (uint32_t)(ctr >> 32), 0x0u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), r);
-        const float u1 = fmaxf((float)(r[0] >> 8) * (1.0f / 16777216.0f), 1e-7f);
-        const float u2 = (float)(r[1] >> 8) * (1.0f / 16777216.0f);
-        const float nrm = sqrtf(-2.f * logf(u1)) * cosf(6.2831853f * u2);
         const float sg = a.sigma != nullptr ? a.sigma[i / a.A] : a.sigma_const;
-        float x = a.x[i];
-        x = x + a.theta * (a.mu - x) + sg * nrm;
+        const float x = ou_advance(a.x[i], (uint32_t)i, ctr, a.seed, a.theta, a.mu, sg);
         a.x[i] = x;
-        a.out[i] = fminf(a.high, fmaxf(a.low, a.action[i] + x));
+        a.out[i] = ou_apply(a.action[i], x, a.low, a.high);
     }
 }
 __global__ void ou_counter_kernel(unsigned long long* c) {

@@ -19,6 +19,7 @@ struct PlanarEnvArgs {
     float* noise;            // [E][ld_act] exploration-noise state, zeroed where an episode ends; or null
     double* stats;           // [2] sum of finished episode returns, number of finished episodes
     unsigned long long* counter;
+    unsigned long long* counter_next;   // null: a follow-up launch increments `counter` in place; else this launch leaves counter + 1 here
     float* terrain;          // [200][E] ground heights of the walker (sample-major: a wavefront's 64 environments read and
                              // write one sample as one 256-byte access), redrawn at every reset; null: flat ground
     unsigned long long seed;
@@ -36,6 +37,7 @@ __global__ __launch_bounds__(64) void planar_step_kernel(const PlanarEnvArgs a) 
     constexpr int L = T::L, n = L + 2;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned long long ctr = *a.counter;
+    next_counter(a.counter_next, ctr);
     if (e >= a.E) return;
     const PlanarParams* P = a.P;
     float* st = a.state + (size_t)e * STRIDE;
@@ -137,7 +139,7 @@ int launch(const PlanarEnvArgs* a, const PlanarParams* host, hipStream_t stream)
         host->contact_links != T::CL)
         return -3;       // the host model is not the mechanism this kernel was compiled for
     hipLaunchKernelGGL(planar_step_kernel<T>, dim3((a->E + 63) / 64), dim3(64), 0, stream, *a);
-    hipLaunchKernelGGL(counter_kernel, dim3(1), dim3(64), 0, stream, a->counter);
+    if (a->counter_next == nullptr) hipLaunchKernelGGL(counter_kernel, dim3(1), dim3(64), 0, stream, a->counter);
     return (int)hipGetLastError();
 }
 }  // namespace planar

@@ -10,6 +10,7 @@
 //  d4pg_ipc_*            : hipIpc memory handles, so that an agent process reads the learner's weights in
 //                          place (what torch's share_memory() gives the reference on CUDA,
 //                          models/d4pg/engine.py:129-144)
+#include <vector>
 #include <string.h>
 
 #include "common.h"
@@ -63,6 +64,7 @@ struct PendulumArgs {
     float* noise;            // [E][ld_act] exploration-noise state, zeroed where an episode ends; or null
     double* stats;           // [2] sum of finished episode returns, number of finished episodes
     unsigned long long* counter;   // device counter: one increment per call (Philox stream position)
+    unsigned long long* counter_next;   // null: a follow-up launch increments `counter` in place; else this launch leaves counter + 1 here
     unsigned long long seed;
     int E, ld_act, time_limit, init;     // init: 1 = reset every environment instead of stepping
     float reward_scale;
@@ -72,6 +74,7 @@ struct PendulumArgs {
 __global__ __launch_bounds__(256) void pendulum_step_kernel(const PendulumArgs a) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned long long ctr = *a.counter;
+    next_counter(a.counter_next, ctr);
     if (e >= a.E) return;
     const float max_speed = 8.f, max_torque = 2.f, dt = 0.05f, g = 10.f, m = 1.f, l = 1.f, pi = 3.14159265358979f;
     float th = a.theta[e], thd = a.theta_dot[e];
@@ -121,13 +124,36 @@ __global__ __launch_bounds__(256) void pendulum_step_kernel(const PendulumArgs a
 __global__ void rollout_counter_kernel(unsigned long long* c) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *c += 1;
 }
+// Paired counter slots: a sequence of an odd number of steps ends in the other slot; this brings it back, so that a
+// captured sequence always starts from the slot it was captured with.
+__global__ void rollout_counter_copy_kernel(unsigned long long* dst, const unsigned long long* src) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *dst = *src;
+}
+// Kernel nodes of a captured graph: what a replay launches (tests and benches count launches per environment step).
+D4PG_API int d4pg_graph_kernel_nodes(hipGraph_t g) {
+    size_t n = 0;
+    if (g == nullptr || hipGraphGetNodes(g, nullptr, &n) != hipSuccess) return -1;
+    std::vector<hipGraphNode_t> nodes(n);
+    if (n > 0 && hipGraphGetNodes(g, nodes.data(), &n) != hipSuccess) return -1;
+    int k = 0;
+    for (size_t i = 0; i < n; ++i) {
+        hipGraphNodeType t;
+        if (hipGraphNodeGetType(nodes[i], &t) == hipSuccess && t == hipGraphNodeTypeKernel) ++k;
+    }
+    return k;
+}
+D4PG_API int d4pg_counter_copy(unsigned long long* dst, const unsigned long long* src, hipStream_t stream) {
+    if (dst == nullptr || src == nullptr || dst == src) return -1;
+    hipLaunchKernelGGL(rollout_counter_copy_kernel, dim3(1), dim3(64), 0, stream, dst, src);
+    return (int)hipGetLastError();
+}
 D4PG_API int d4pg_pendulum_step(const PendulumArgs* a, hipStream_t stream) {
     if (a->E < 1 || a->theta == nullptr || a->obs == nullptr || a->counter == nullptr) return -1;
     if (!a->init && (a->action == nullptr || a->next_obs == nullptr || a->reward == nullptr || a->done == nullptr ||
                      a->trunc == nullptr || a->stats == nullptr || a->ld_act < 1))
         return -2;
     hipLaunchKernelGGL(pendulum_step_kernel, dim3((a->E + 255) / 256), dim3(256), 0, stream, *a);
-    hipLaunchKernelGGL(rollout_counter_kernel, dim3(1), dim3(64), 0, stream, a->counter);
+    if (a->counter_next == nullptr) hipLaunchKernelGGL(rollout_counter_kernel, dim3(1), dim3(64), 0, stream, a->counter);
     return (int)hipGetLastError();
 }
 
@@ -147,6 +173,7 @@ struct CartPoleArgs {
     float* noise;            // [E][ld_act] exploration-noise state, zeroed where an episode ends; or null
     double* stats;           // [2] sum of finished episode returns, number of finished episodes
     unsigned long long* counter;
+    unsigned long long* counter_next;   // null: a follow-up launch increments `counter` in place; else this launch leaves counter + 1 here
     unsigned long long seed;
     int E, ld_act, time_limit, init;
     int limit_terminal;
@@ -155,6 +182,7 @@ struct CartPoleArgs {
 __global__ __launch_bounds__(256) void cartpole_step_kernel(const CartPoleArgs a) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned long long ctr = *a.counter;
+    next_counter(a.counter_next, ctr);
     if (e >= a.E) return;
     const float gravity = 9.8f, masscart = 1.f, masspole = 0.1f, length = 0.5f, force_mag = 10.f, tau = 0.02f;
     float x = a.state[e * 4 + 0], xd = a.state[e * 4 + 1], th = a.state[e * 4 + 2], thd = a.state[e * 4 + 3];
@@ -217,7 +245,7 @@ D4PG_API int d4pg_cartpole_step(const CartPoleArgs* a, hipStream_t stream) {
                      a->trunc == nullptr || a->stats == nullptr || a->ld_act < 1))
         return -2;
     hipLaunchKernelGGL(cartpole_step_kernel, dim3((a->E + 255) / 256), dim3(256), 0, stream, *a);
-    hipLaunchKernelGGL(rollout_counter_kernel, dim3(1), dim3(64), 0, stream, a->counter);
+    if (a->counter_next == nullptr) hipLaunchKernelGGL(rollout_counter_kernel, dim3(1), dim3(64), 0, stream, a->counter);
     return (int)hipGetLastError();
 }
 
@@ -238,6 +266,7 @@ struct LanderArgs {
     float* noise;            // [E][ld_act] exploration-noise state, zeroed where an episode ends; or null
     double* stats;           // [2] sum of finished episode returns, number of finished episodes
     unsigned long long* counter;
+    unsigned long long* counter_next;   // null: a follow-up launch increments `counter` in place; else this launch leaves counter + 1 here
     unsigned long long seed;
     int E, ld_act, time_limit, init;
     int limit_terminal;
@@ -270,6 +299,7 @@ __global__ __launch_bounds__(256) void lander_step_kernel(const LanderArgs a) {
     using namespace lander;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned long long ctr = *a.counter;
+    next_counter(a.counter_next, ctr);
     if (e >= a.E) return;
     float* st = a.state + (size_t)e * 12;
     float q[6];
@@ -379,7 +409,7 @@ D4PG_API int d4pg_lander_step(const LanderArgs* a, hipStream_t stream) {
                      a->trunc == nullptr || a->stats == nullptr || a->ld_act < 2))
         return -2;
     hipLaunchKernelGGL(lander_step_kernel, dim3((a->E + 255) / 256), dim3(256), 0, stream, *a);
-    hipLaunchKernelGGL(rollout_counter_kernel, dim3(1), dim3(64), 0, stream, a->counter);
+    if (a->counter_next == nullptr) hipLaunchKernelGGL(rollout_counter_kernel, dim3(1), dim3(64), 0, stream, a->counter);
     return (int)hipGetLastError();
 }
 
@@ -403,6 +433,7 @@ struct SyntheticEnvArgs {
     float* noise;
     double* stats;
     unsigned long long* counter;
+    unsigned long long* counter_next;   // null: a follow-up launch increments `counter` in place; else this launch leaves counter + 1 here
     unsigned long long seed;
     int E, S, A, ld_act, time_limit, init;
     float terminal_prob, noise_std;
@@ -430,6 +461,7 @@ __global__ __launch_bounds__(256) void synthetic_next_kernel(const SyntheticEnvA
 __global__ __launch_bounds__(256) void synthetic_book_kernel(const SyntheticEnvArgs a) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned long long ctr = *a.counter;
+    next_counter(a.counter_next, ctr);
     if (e >= a.E) return;
     float* s = a.state + (size_t)e * a.S;
     int t = a.t[e];
@@ -481,7 +513,7 @@ D4PG_API int d4pg_synthetic_env_step(const SyntheticEnvArgs* a, hipStream_t stre
         hipLaunchKernelGGL(synthetic_next_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, *a);
     }
     hipLaunchKernelGGL(synthetic_book_kernel, dim3((a->E + 255) / 256), dim3(256), 0, stream, *a);
-    hipLaunchKernelGGL(rollout_counter_kernel, dim3(1), dim3(64), 0, stream, a->counter);
+    if (a->counter_next == nullptr) hipLaunchKernelGGL(rollout_counter_kernel, dim3(1), dim3(64), 0, stream, a->counter);
     return (int)hipGetLastError();
 }
 

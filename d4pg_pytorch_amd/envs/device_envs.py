@@ -26,7 +26,7 @@ import numpy as np
 import torch
 
 from ..ops import hip as H
-from .device_pendulum import DevicePendulum
+from .device_pendulum import DevicePendulum, StepCounter
 
 
 class _DeviceEnvBase:
@@ -40,14 +40,15 @@ class _DeviceEnvBase:
         self.state, self.ep_return = z(self.E, self.state_dim), z(self.E)
         self.t = z(self.E, dt=torch.int32)
         self.stats = z(2, dt=torch.float64)
-        self.counter = z(1, dt=torch.int64)
+        self.counter = StepCounter(self.device)
         self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         self.noise: Optional[torch.Tensor] = None
         self._seen = (0.0, 0)
 
     def _fill(self, a, init: int) -> None:
         a.state, a.t, a.ep_return = self.state.data_ptr(), self.t.data_ptr(), self.ep_return.data_ptr()
-        a.stats, a.counter, a.seed = self.stats.data_ptr(), self.counter.data_ptr(), self.seed
+        a.stats, a.seed = self.stats.data_ptr(), self.seed
+        self.counter.fill(a)
         a.E, a.time_limit, a.init = self.E, self.time_limit, init
         if self.noise is not None:
             a.noise, a.ld_act = self.noise.data_ptr(), self.noise.shape[1]

@@ -15,6 +15,44 @@ import torch
 from ..ops import hip as H
 
 
+class StepCounter:
+    """Philox stream position of a device environment (its resets, and the exploration noise of a rollout on it).
+
+    Unpaired (the default): one slot, incremented by a one-thread launch behind every environment launch.
+    Paired: two slots; a step reads the current one and a thread of the environment's own kernel leaves the value + 1
+    in the other (``next_counter`` in ``csrc/common.h``), which the launches of the next step read.  No launch of its
+    own; which slot is current is tracked here, so a captured sequence must end on the slot it started from
+    (:meth:`rewind`).
+    """
+
+    def __init__(self, device):
+        self.slots = torch.zeros(2, dtype=torch.int64, device=device)
+        self.cur, self.paired = 0, False
+
+    @property
+    def ptr(self) -> int:
+        """Address of the slot the next launches read."""
+        return self.slots.data_ptr() + 8 * self.cur
+
+    def fill(self, a) -> None:
+        """Counter fields of an environment's argument struct; call once per environment launch."""
+        a.counter = self.ptr
+        if self.paired:
+            a.counter_next = self.slots.data_ptr() + 8 * (self.cur ^ 1)
+            self.cur ^= 1
+
+    def rewind(self) -> None:
+        """Bring the position back to slot 0 (one tiny launch after an odd number of paired steps, none otherwise)."""
+        if self.cur == 1:
+            base = self.slots.data_ptr()
+            H._check(H.lib().d4pg_counter_copy(base, base + 8, H.stream_ptr()), "d4pg_counter_copy")
+            self.cur = 0
+
+    def value(self) -> int:
+        """Synchronises."""
+        return int(self.slots[self.cur].item())
+
+
 class DevicePendulum:
     state_dim, action_dim = 3, 1
     reward_scale = 100.0
@@ -26,7 +64,7 @@ class DevicePendulum:
         self.theta, self.theta_dot, self.ep_return = z(self.E), z(self.E), z(self.E)
         self.t = z(self.E, dt=torch.int32)
         self.stats = z(2, dt=torch.float64)
-        self.counter = z(1, dt=torch.int64)
+        self.counter = StepCounter(self.device)
         self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         self._seen = (0.0, 0)
         self.limit_terminal = bool(limit_terminal)      # like PendulumVec: the 200-step limit reads as done
@@ -36,7 +74,8 @@ class DevicePendulum:
         a = H.PendulumArgs()
         a.theta, a.theta_dot, a.t, a.ep_return = (self.theta.data_ptr(), self.theta_dot.data_ptr(), self.t.data_ptr(),
                                                   self.ep_return.data_ptr())
-        a.stats, a.counter, a.seed = self.stats.data_ptr(), self.counter.data_ptr(), self.seed
+        a.stats, a.seed = self.stats.data_ptr(), self.seed
+        self.counter.fill(a)
         a.E, a.time_limit, a.init, a.reward_scale = self.E, self.time_limit, init, self.reward_scale
         a.limit_terminal = int(self.limit_terminal)
         if self.noise is not None:

@@ -262,10 +262,15 @@ class WgradGroup32(C.Structure):
                 ("tree", vp)]
 
 
+class OuFuse32(C.Structure):
+    _fields_ = [("x", vp), ("counter", vp), ("seed", C.c_ulonglong), ("theta", C.c_float), ("mu", C.c_float),
+                ("sigma", C.c_float), ("low", C.c_float), ("high", C.c_float), ("pad_", C.c_int)]
+
+
 class ActorInferArgs32(C.Structure):
     _fields_ = [("l", LayerW32 * 3), ("obs", vp), ("act", vp), ("E", C.c_int), ("S", C.c_int), ("A", C.c_int),
                 ("H", C.c_int), ("ld_obs", C.c_int), ("ld_act", C.c_int), ("ldx", C.c_int), ("ldh", C.c_int),
-                ("action_scale", C.c_float), ("pad_", C.c_int)]
+                ("action_scale", C.c_float), ("pad_", C.c_int), ("ou", OuFuse32)]
 
 
 # ---- device-resident rollouts, weight hand-off (csrc/rollout.hip) ----
@@ -280,21 +285,21 @@ class PackActorArgs32(C.Structure):
 
 class PendulumArgs(C.Structure):
     _fields_ = [("theta", vp), ("theta_dot", vp), ("t", vp), ("ep_return", vp), ("action", vp), ("obs", vp),
-                ("next_obs", vp), ("reward", vp), ("done", vp), ("trunc", vp), ("noise", vp), ("stats", vp), ("counter", vp),
+                ("next_obs", vp), ("reward", vp), ("done", vp), ("trunc", vp), ("noise", vp), ("stats", vp), ("counter", vp), ("counter_next", vp),
                 ("seed", C.c_ulonglong), ("E", C.c_int), ("ld_act", C.c_int), ("time_limit", C.c_int), ("init", C.c_int),
                 ("reward_scale", C.c_float), ("limit_terminal", C.c_int)]
 
 
 class CartPoleArgs(C.Structure):
     _fields_ = [("state", vp), ("t", vp), ("ep_return", vp), ("action", vp), ("obs", vp), ("next_obs", vp),
-                ("reward", vp), ("done", vp), ("trunc", vp), ("noise", vp), ("stats", vp), ("counter", vp),
+                ("reward", vp), ("done", vp), ("trunc", vp), ("noise", vp), ("stats", vp), ("counter", vp), ("counter_next", vp),
                 ("seed", C.c_ulonglong), ("E", C.c_int), ("ld_act", C.c_int), ("time_limit", C.c_int), ("init", C.c_int),
                 ("limit_terminal", C.c_int), ("pad_", C.c_int)]
 
 
 class LanderArgs(C.Structure):
     _fields_ = [("state", vp), ("t", vp), ("ep_return", vp), ("action", vp), ("obs", vp), ("next_obs", vp),
-                ("reward", vp), ("done", vp), ("trunc", vp), ("noise", vp), ("stats", vp), ("counter", vp),
+                ("reward", vp), ("done", vp), ("trunc", vp), ("noise", vp), ("stats", vp), ("counter", vp), ("counter_next", vp),
                 ("seed", C.c_ulonglong), ("E", C.c_int), ("ld_act", C.c_int), ("time_limit", C.c_int), ("init", C.c_int),
                 ("limit_terminal", C.c_int), ("reward_scale", C.c_float)]
 
@@ -314,7 +319,7 @@ class PlanarParams(C.Structure):
 
 class PlanarEnvArgs(C.Structure):
     _fields_ = [("P", vp), ("state", vp), ("t", vp), ("ep_return", vp), ("action", vp), ("obs", vp), ("next_obs", vp),
-                ("reward", vp), ("done", vp), ("trunc", vp), ("noise", vp), ("stats", vp), ("counter", vp), ("terrain", vp),
+                ("reward", vp), ("done", vp), ("trunc", vp), ("noise", vp), ("stats", vp), ("counter", vp), ("counter_next", vp), ("terrain", vp),
                 ("seed", C.c_ulonglong), ("E", C.c_int), ("ld_act", C.c_int), ("time_limit", C.c_int), ("init", C.c_int),
                 ("limit_terminal", C.c_int), ("kind", C.c_int), ("reward_scale", C.c_float), ("hilly", C.c_int)]
 
@@ -335,14 +340,14 @@ class AntParams(C.Structure):
 
 class AntEnvArgs(C.Structure):
     _fields_ = [("P", vp), ("state", vp), ("t", vp), ("ep_return", vp), ("action", vp), ("obs", vp), ("next_obs", vp),
-                ("reward", vp), ("done", vp), ("trunc", vp), ("noise", vp), ("stats", vp), ("counter", vp),
+                ("reward", vp), ("done", vp), ("trunc", vp), ("noise", vp), ("stats", vp), ("counter", vp), ("counter_next", vp),
                 ("seed", C.c_ulonglong), ("E", C.c_int), ("ld_act", C.c_int), ("time_limit", C.c_int), ("init", C.c_int),
                 ("limit_terminal", C.c_int), ("reward_scale", C.c_float)]
 
 
 class AnalyticEnvArgs(C.Structure):
     _fields_ = [("state", vp), ("t", vp), ("ep_return", vp), ("action", vp), ("obs", vp), ("next_obs", vp),
-                ("reward", vp), ("done", vp), ("trunc", vp), ("noise", vp), ("stats", vp), ("counter", vp),
+                ("reward", vp), ("done", vp), ("trunc", vp), ("noise", vp), ("stats", vp), ("counter", vp), ("counter_next", vp),
                 ("seed", C.c_ulonglong), ("E", C.c_int), ("ld_act", C.c_int), ("time_limit", C.c_int), ("init", C.c_int),
                 ("limit_terminal", C.c_int), ("kind", C.c_int), ("reward_scale", C.c_float)]
 
@@ -350,7 +355,7 @@ class AnalyticEnvArgs(C.Structure):
 class SyntheticEnvArgs(C.Structure):
     _fields_ = [("state", vp), ("t", vp), ("ep_return", vp), ("M", vp), ("N", vp), ("action", vp), ("obs", vp),
                 ("next_obs", vp), ("reward", vp), ("done", vp), ("trunc", vp), ("noise", vp), ("stats", vp),
-                ("counter", vp), ("seed", C.c_ulonglong), ("E", C.c_int), ("S", C.c_int), ("A", C.c_int),
+                ("counter", vp), ("counter_next", vp), ("seed", C.c_ulonglong), ("E", C.c_int), ("S", C.c_int), ("A", C.c_int),
                 ("ld_act", C.c_int), ("time_limit", C.c_int), ("init", C.c_int), ("terminal_prob", C.c_float),
                 ("noise_std", C.c_float)]
 
@@ -440,6 +445,8 @@ def lib() -> C.CDLL:
             ("d4pg_wgrad", [C.POINTER(WgradGroup), vp]),
             ("d4pg_ou_noise", [C.POINTER(OuArgs), vp]),
             ("d4pg_ou_noise_shared_counter", [C.POINTER(OuArgs), vp]),
+            ("d4pg_counter_copy", [vp, vp, vp]),
+            ("d4pg_graph_kernel_nodes", [vp]),
             ("d4pg_critic_phase32", [C.POINTER(CriticPhaseArgs32), C.c_int, vp]),
             ("d4pg_actor_phase32", [C.POINTER(ActorPhaseArgs32), C.c_int, vp]),
             ("d4pg_phase32_lds_bytes", [C.POINTER(PhaseDims), C.c_int, C.c_int]),
@@ -521,6 +528,14 @@ def gemm_group(descs: Sequence[GemmDesc], stream: Optional[torch.cuda.Stream] = 
         g.p[i] = d
     g.count = len(descs)
     _check(lib().d4pg_gemm_group(C.byref(g), stream_ptr(stream)), "d4pg_gemm_group")
+
+
+def graph_kernel_nodes(graph: "torch.cuda.CUDAGraph") -> int:
+    """Kernel launches one replay of ``graph`` makes (a graph captured with ``keep_graph=True``)."""
+    n = lib().d4pg_graph_kernel_nodes(graph.raw_cuda_graph())
+    if n < 0:
+        raise RuntimeError("hipGraphGetNodes failed")
+    return int(n)
 
 
 def launch(name: str, args: C.Structure, stream: Optional[torch.cuda.Stream] = None) -> None:

@@ -90,13 +90,15 @@ class GreedyEvaluator:
 def train_on_device(model: str = "d4pg", core: str = "fp32", updates: int = 20_000, seed: int = 0,
                     eval_every: int = 1000, envs: int = 8, segment: int = 32, eval_envs: int = 64,
                     warmup_segments: int = 8, device="cuda", env: str = "Pendulum-v0", return_actor: bool = False,
-                    **overrides) -> Dict:
+                    overlap: bool = False, **overrides) -> Dict:
     """Train on a device-resident environment (the pendulum by default; any id ``envs/device_envs.py::make_device_env``
     knows: the lunar lander, the articulated-body tasks, ...); returns the evaluation curve and summary numbers.
 
     ``core``: ``"torch"`` (eager PyTorch fp32, the oracle), ``"fp32"`` (fused HIP, default compute path) or
     ``"bf16"`` (fused HIP, bf16 MFMA operands).  ``envs * segment`` environment steps are collected per 32
-    updates (8 per update by default)."""
+    updates (8 per update by default).  ``overlap``: the next segment runs on the rollout's stream BESIDE the 32 updates
+    (its policy is then 32 updates old, as an explorer process's is between two weight publications) instead of ahead
+    of them; the learner's own loop (``models/learner.py``) works this way."""
     from ..actors.gpu_rollout import DeviceRollout
     from ..envs.device_envs import make_device_env
     from ..models.core import build_core
@@ -127,8 +129,11 @@ def train_on_device(model: str = "d4pg", core: str = "fp32", updates: int = 20_0
         if step >= next_eval:
             curve.append((step, ev(c.target.flat.data_ptr(), base_a)))
             next_eval += eval_every
-        ro.refresh_weights(c.online.flat.data_ptr(), base_a)
-        ro.collect()
+        if overlap:
+            ro.collect_overlapped(c.online.flat.data_ptr(), base_a)      # rows of the last segment in, the next one off
+        else:
+            ro.refresh_weights(c.online.flat.data_ptr(), base_a)
+            ro.collect()
         n = min(32, updates - step)
         if fused:
             done = 0
@@ -138,6 +143,7 @@ def train_on_device(model: str = "d4pg", core: str = "fp32", updates: int = 20_0
             for _ in range(n):
                 c.update(sampler())
         step += n
+    ro.drain()
     curve.append((step, ev(c.target.flat.data_ptr(), base_a)))
     torch.cuda.synchronize()
     wall = time.time() - t0

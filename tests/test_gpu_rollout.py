@@ -97,7 +97,7 @@ def test_device_pendulum_follows_the_host_pendulum():
             host.theta_dot[:] = dev.theta_dot.cpu().double().numpy()
 
 
-def _rollout(explore, use_graph, n=5, T=16, E=96, seed=5, prioritized=0):
+def _rollout(explore, use_graph, n=5, T=16, E=96, seed=5, prioritized=0, fuse_noise=True):
     from d4pg_pytorch_amd.actors.gpu_rollout import DeviceRollout
     from d4pg_pytorch_amd.envs.device_pendulum import DevicePendulum
     from d4pg_pytorch_amd.models.core import build_core
@@ -108,7 +108,8 @@ def _rollout(explore, use_graph, n=5, T=16, E=96, seed=5, prioritized=0):
     core = build_core(cfg, "cuda")
     rp = HbmReplay(cfg, "cuda", core.dev_state)
     env = DevicePendulum(E, "cuda", seed=seed, time_limit=20)       # several episode ends inside a segment
-    ro = DeviceRollout(cfg, env, rp, "cuda", segment=T, seed=seed, explore=explore, use_graph=use_graph)
+    ro = DeviceRollout(cfg, env, rp, "cuda", segment=T, seed=seed, explore=explore, use_graph=use_graph,
+                       fuse_noise=fuse_noise)
     ro.refresh_weights(core.online.flat.data_ptr(), core.layout.actor.base)
     return cfg, core, rp, ro
 
@@ -144,6 +145,26 @@ def test_rollout_rows_equal_the_host_nstep_assembler(use_graph):
     assert rp.size == 3 * T * E and core.read_dev_state().replay_size == 3 * T * E
     # rows in the replay are those rows
     assert torch.equal(rp.rows[2 * T * E: 3 * T * E], ro.rows)
+
+
+@pytest.mark.parametrize("T", [16, 15])
+def test_two_launches_per_step_and_the_same_rows_as_separate_noise_and_counter_launches(T):
+    """The segment graph holds T x (policy with the noise in its epilogue, environment that advances its own counter) and
+    the per-segment launches; it produces bit for bit the rows of T x (policy, noise, environment, counter)."""
+    _, _, _, fused = _rollout(explore=True, use_graph=True, T=T)
+    _, _, _, apart = _rollout(explore=True, use_graph=True, T=T, fuse_noise=False)
+    assert fused.fuse_noise and not apart.fuse_noise
+    for _ in range(4):                              # resets (20-step episodes) draw from the same counter positions too
+        fused.collect()
+        apart.collect()
+        torch.cuda.synchronize()
+        assert torch.equal(fused.rows, apart.rows)
+        assert torch.equal(fused.ou_x[:, : fused.A], apart.ou_x[:, : apart.A])
+    assert fused.env.counter.value() == apart.env.counter.value() == 1 + 4 * T
+    # per segment: n-step targets, rows (+ the counter's way back if T is odd); the first observations move in a copy node
+    assert fused.graph_kernels == 2 * T + 2 + (T % 2), fused.graph_kernels
+    assert apart.graph_kernels == 4 * T + 2, apart.graph_kernels
+    assert fused.launches_per_step < 2.3 and apart.launches_per_step > 4.0
 
 
 def test_rollout_without_noise_plays_the_policy_and_graph_equals_eager():
