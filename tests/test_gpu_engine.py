@@ -39,6 +39,36 @@ def test_hbm_topology_trains_on_the_gpu(tmp_path, model, per):
     assert glob.glob(os.path.join(exp, "agent_0", "local_episode_*_reward_*.pt"))
 
 
+@pytest.mark.parametrize("width", [300, 64])
+def test_any_hidden_width_runs_the_fused_kernels_through_the_whole_topology(tmp_path, width):
+    """The reference takes any ``dense_size`` (models/d4pg/networks.py:10,23-25; its own test file uses 100).  Widths
+    outside the compile-time classes run the 16x16x4 kernels: learner (graph, PER through the HBM replay), GPU
+    exploiter with single-launch inference and device explorers, end to end."""
+    from d4pg_pytorch_amd.actors.gpu_actor import GpuActor
+    from d4pg_pytorch_amd.models.core import build_core
+    cfg = dict(env="Pendulum-v0", model="d4pg", num_agents=2, batch_size=128, num_steps_train=600,
+               replay_mem_size=20_000, n_step_returns=5, device="cuda", agent_device="cuda", dense_size=width,
+               v_min=-20, v_max=0, replay_memory_prioritized=1, metrics_interval=100, weight_publish_interval=50,
+               envs_per_agent=4, gpu_rollout_envs=32, gpu_rollout_segment=32, num_episode_save=1000,
+               results_path=str(tmp_path / "results"))
+    core = build_core(default_config(**{k: v for k, v in cfg.items() if k != "results_path"}), "cuda")
+    assert type(core).__name__ == "HipCoreF32" and core.wide
+    assert GpuActor(3, 1, width, max_batch=8).launches_per_act == 1
+    del core
+    engine = load_engine(cfg)
+    exp = engine.train()
+    assert engine.final_update_step == 600
+    assert all(c == 0 for c in engine.exit_codes.values()), engine.exit_codes
+    ev = read_events(os.path.join(exp, "learner"))
+    assert all(np.isfinite(e[3]) for e in ev)
+    losses = [e[3] for e in ev if e[2] == "learner/value_loss"]
+    assert len(losses) >= 4 and losses[-1] < losses[0]          # the critic fits its targets
+    assert engine.final_env_steps >= 32 * 32
+    b = load_learner_bundle(os.path.join(exp, "learner", "checkpoint_final.pt"))
+    assert any(tuple(v.shape) == (width, width) for v in b["critic"].values())
+    assert all(torch.isfinite(v).all() for v in b["critic"].values())
+
+
 def test_gpu_actor_matches_cpu_actor():
     from d4pg_pytorch_amd.actors.gpu_actor import GpuActor
     from d4pg_pytorch_amd.actors.native import CpuActor
