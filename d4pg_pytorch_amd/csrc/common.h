@@ -107,6 +107,19 @@ __device__ __forceinline__ float wave_min(float v) {
 }
 
 // Philox-4x32-10 counter-based generator (one call = 4 x 32 random bits).
+// Adam (torch.optim.Adam's arithmetic: models/d4pg/d4pg.py:55-56 of the reference) and the Polyak average of the
+// target (d4pg.py:126-138) for one parameter.  ONE definition for the optimiser fused into the weight-gradient kernels
+// and for the stand-alone kernel of the gradient-exchange mode, contraction off: the two round alike, so a world of
+// one reproduces the fused path bit for bit.
+__device__ __forceinline__ void adam_polyak_math(float& m, float& v, float& p, float& t, float g, float beta1, float beta2,
+                                                 float eps, float tau, float step_size, float inv_sqrt_bc2) {
+#pragma clang fp contract(off)
+    m = beta1 * m + (1.f - beta1) * g;
+    v = beta2 * v + (1.f - beta2) * g * g;
+    p = p - step_size * (m / (sqrtf(v) * inv_sqrt_bc2 + eps));
+    t = (1.f - tau) * t + tau * p;
+}
+
 // The step counter of a device environment (the Philox stream position of its resets and of the exploration noise) can
 // be a PAIR of slots: a step reads one and one thread leaves counter + 1 in the other, which the kernels of the next
 // step read.  No launch of its own, and no kernel reads a slot that a kernel of the same step writes.

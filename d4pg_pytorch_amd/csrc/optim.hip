@@ -115,24 +115,18 @@ __global__ __launch_bounds__(256) void adam_polyak_kernel(const AdamPolyakArgs a
         f32x4 g = reinterpret_cast<const f32x4*>(a.g)[i];
         f32x4 m = reinterpret_cast<f32x4*>(a.m)[i];
         f32x4 v = reinterpret_cast<f32x4*>(a.v)[i];
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        if (a.t != nullptr) t = reinterpret_cast<f32x4*>(a.t)[i];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float gk = g[k] * a.gscale;
-            m[k] = a.beta1 * m[k] + (1.f - a.beta1) * gk;
-            v[k] = a.beta2 * v[k] + (1.f - a.beta2) * gk * gk;
-            const float denom = sqrtf(v[k]) * inv_sqrt_bc2 + a.eps;
-            p[k] = p[k] - step_size * (m[k] / denom);
+            float mk = m[k], vk = v[k], pk = p[k], tk = t[k];
+            adam_polyak_math(mk, vk, pk, tk, g[k] * a.gscale, a.beta1, a.beta2, a.eps, a.tau, step_size, inv_sqrt_bc2);
+            m[k] = mk, v[k] = vk, p[k] = pk, t[k] = tk;
         }
         reinterpret_cast<f32x4*>(a.p)[i] = p;
         reinterpret_cast<f32x4*>(a.m)[i] = m;
         reinterpret_cast<f32x4*>(a.v)[i] = v;
-        f32x4 t = {0.f, 0.f, 0.f, 0.f};
-        if (a.t != nullptr) {
-            t = reinterpret_cast<f32x4*>(a.t)[i];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) t[k] = (1.f - a.tau) * t[k] + a.tau * p[k];
-            reinterpret_cast<f32x4*>(a.t)[i] = t;
-        }
+        if (a.t != nullptr) reinterpret_cast<f32x4*>(a.t)[i] = t;
         if (a.sh.count > 0) write_shadows(a.sh, i * 4, p, t, a.t != nullptr);
     }
     // step_done is read only by the first kernel of the next update

@@ -138,28 +138,22 @@ __device__ __forceinline__ AdamState adam_fetch(const WgradAdam& o, long long id
 }
 __device__ __forceinline__ float adam_apply(const WgradAdam& o, long long idx, const AdamState& s, float g,
                                             float step_size, float inv_sqrt_bc2, float& t_out) {
-    float m = s.m, v = s.v, p = s.p;
-    m = o.beta1 * m + (1.f - o.beta1) * g;
-    v = o.beta2 * v + (1.f - o.beta2) * g * g;
-    p = p - step_size * (m / (sqrtf(v) * inv_sqrt_bc2 + o.eps));
+    float m = s.m, v = s.v, p = s.p, t = s.t;
+    adam_polyak_math(m, v, p, t, g, o.beta1, o.beta2, o.eps, o.tau, step_size, inv_sqrt_bc2);
     o.m[idx] = m;
     o.v[idx] = v;
     o.p[idx] = p;
-    const float t = (1.f - o.tau) * s.t + o.tau * p;
     o.t[idx] = t;
     t_out = t;
     return p;
 }
 __device__ __forceinline__ float adam_elem(const WgradAdam& o, long long idx, float g, float step_size,
                                            float inv_sqrt_bc2, float& t_out) {
-    float m = o.m[idx], v = o.v[idx], p = o.p[idx];
-    m = o.beta1 * m + (1.f - o.beta1) * g;
-    v = o.beta2 * v + (1.f - o.beta2) * g * g;
-    p = p - step_size * (m / (sqrtf(v) * inv_sqrt_bc2 + o.eps));
+    float m = o.m[idx], v = o.v[idx], p = o.p[idx], t = o.t[idx];
+    adam_polyak_math(m, v, p, t, g, o.beta1, o.beta2, o.eps, o.tau, step_size, inv_sqrt_bc2);
     o.m[idx] = m;
     o.v[idx] = v;
     o.p[idx] = p;
-    const float t = (1.f - o.tau) * o.t[idx] + o.tau * p;
     o.t[idx] = t;
     t_out = t;
     return p;

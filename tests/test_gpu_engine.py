@@ -62,7 +62,8 @@ def test_any_hidden_width_runs_the_fused_kernels_through_the_whole_topology(tmp_
     ev = read_events(os.path.join(exp, "learner"))
     assert all(np.isfinite(e[3]) for e in ev)
     losses = [e[3] for e in ev if e[2] == "learner/value_loss"]
-    assert len(losses) >= 4 and losses[-1] < losses[0]          # the critic fits its targets
+    # the critic fits its targets: the cross-entropy of an untrained critic against a projected target is ln 51 = 3.9
+    assert len(losses) >= 4 and max(losses[1:]) < 1.0, losses
     assert engine.final_env_steps >= 32 * 32
     b = load_learner_bundle(os.path.join(exp, "learner", "checkpoint_final.pt"))
     assert any(tuple(v.shape) == (width, width) for v in b["critic"].values())
@@ -121,16 +122,11 @@ def test_data_parallel_wiring_on_one_gpu(dtype):
                 want = torch.zeros_like(core.shadow_online)
                 refresh_shadows(core.online.flat.detach(), want, core.layout, core.sl)
                 assert torch.equal(core.shadow_online, want)
-        # the optimiser runs in two different kernels (fused into the weight-gradient kernel / stand-alone) whose
-        # multiply-add contraction may differ in the last bit: one update agrees to an ulp; later, fp32 stays
-        # within rounding while bf16's rounding of the weights amplifies it into Adam-step-sized differences
-        torch.testing.assert_close(outs[1][0][0], outs[1][1][0], rtol=0, atol=1e-7)
-        torch.testing.assert_close(outs[1][0][1], outs[1][1][1], rtol=0, atol=1e-7)
-        diff = (outs[10][0][0] - outs[10][1][0]).abs()
-        if dtype == "fp32":
-            assert diff.max().item() < 5e-5 and diff.mean().item() < 2e-6, (diff.max().item(), diff.mean().item())
-        else:
-            assert diff.max().item() < 10 * 5e-4 and diff.mean().item() < 5e-5
+        # the optimiser runs in two different kernels (fused into the weight-gradient kernel / stand-alone) that share
+        # one contraction-free definition of the arithmetic (adam_polyak_math, csrc/common.h): bit-identical
+        for it in (1, 10):
+            assert torch.equal(outs[it][0][0], outs[it][1][0]), (it, (outs[it][0][0] - outs[it][1][0]).abs().max().item())
+            assert torch.equal(outs[it][0][1], outs[it][1][1]), it
     finally:
         comm.close()
 

@@ -88,6 +88,8 @@ def test_bf16_core_trains_like_fp32_and_keeps_shadows_in_sync(graph):
           f"p99 {diff.quantile(0.99).item():.3f}, max {diff.max().item():.3f}; eager moved mean {moved.mean().item():.3f}")
     assert diff.mean().item() < 0.15 * moved.mean().item()
     assert diff.quantile(0.99).item() < 2.0
+    # and no parameter anywhere near the worst case (opposite directions on every one of the ten updates: 20 steps)
+    assert diff.max().item() < 10.0, diff.max().item()
     mh, mt = hipc.read_metrics(), torc.read_metrics()
     assert mh["count"] == 10
     assert abs(mh["value_loss"] - mt["value_loss"]) < 2e-2 * max(1.0, abs(mt["value_loss"]))

@@ -118,9 +118,18 @@ def test_engine_trains_the_pendulum_from_rollout_workers(tmp_path):
     assert set(engine.exit_codes) == {"learner-0", "agent-0", "rollout-0"}
     assert engine.final_env_steps >= 20_000 * 8 - 64 * 32
     rewards = [e[3] for e in read_events(os.path.join(exp, "agent-0")) if e[2] == "agent/reward"]
-    assert len(rewards) >= 8 and min(rewards[:4]) < -1000, rewards
-    # the exploiter plays the (slow, tau = 0.001) target policy; a random policy scores about -1200
-    assert max(rewards[len(rewards) // 2:]) > -400.0, rewards
+    assert len(rewards) >= 4 and min(rewards[:4]) < -1000, rewards        # the exploiter followed through the IPC slots
+    # What was learned, measured the way tests/test_learning_gpu.py measures it: the checkpointed TARGET policy, played
+    # greedily on 64 fresh device pendulums (the exploiter's own few episodes race a two-second run; a random policy
+    # scores about -1200).
+    from d4pg_pytorch_amd.models.nets import ActorPolicy
+    from d4pg_pytorch_amd.utils.checkpoint import load_learner_bundle
+    from d4pg_pytorch_amd.utils.learning import GreedyEvaluator
+    bundle = load_learner_bundle(os.path.join(exp, "learner", "checkpoint_final.pt"))
+    pol = ActorPolicy(3, 1, 400, "cuda")
+    pol.load_state_dict(bundle["target_actor"])
+    ret = GreedyEvaluator(engine.config, 64, "cuda", 7)(pol.flat.data_ptr(), 0)
+    assert ret > -400.0, (ret, rewards)
 
 
 def _crash_once_rollout_entry(config, ctrl_name, k, device_index, hb_slot):
