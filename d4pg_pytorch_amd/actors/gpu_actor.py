@@ -29,7 +29,11 @@ from ..models.nets import NetLayout, NetView, Packed32, pad4, pad16, pad32
 from ..ops import hip as H
 
 LDS_PAD32 = 4
-FUSED_HIDDEN_CHUNKS = (4, 8, 13)
+
+
+def has_narrow_kernels(hidden: int) -> bool:
+    """Whether the library holds 4x4x1 kernels compiled for this hidden width (``D4PG_KSH_LIST``, csrc/fused32.hip)."""
+    return bool(H.lib().d4pg_phase32_has_width(pad32(hidden) // 32))
 
 
 class PackedActor32:
@@ -43,7 +47,7 @@ class PackedActor32:
         waves = H.lib().d4pg_phase32_waves()
         # hidden widths the 4x4x1 kernels are compiled for take them; every other width the 16x16x4 kernel
         # (csrc/mlp16_dev.h: any width at run time, tiles of 8 / 16 environments)
-        self.wide = not (pad32(hidden) // 32 in FUSED_HIDDEN_CHUNKS and pad32(state_dim) <= 128)
+        self.wide = not (has_narrow_kernels(hidden) and pad32(state_dim) <= 128)
         off = 0
         self.packed = []
         for i, s in enumerate(self.layout.layers):

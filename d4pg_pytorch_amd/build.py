@@ -102,7 +102,7 @@ def torch_lib_dir() -> str:
 
 #: translation units of csrc/fused.hip / csrc/fused32.hip: -1 = C API + weight gradients, the others one
 #: hidden width each (0 = the run-time-width variants: bf16 pipeline, and the 16x16x4 path of the fp32 pipeline)
-FUSED_PARTS = {"fused.hip": (-1, 13, 4, 8, 0), "fused32.hip": (-1, 13, 4, 8, 0)}
+FUSED_PARTS = {"fused.hip": (-1, 13, 4, 8, 0), "fused32.hip": (-1, 13, 4, 8, 2, 7, 10, 16, 0)}
 
 
 #: optimisation level per source where it is not -O3.  ant_env.hip: -O1 is the FASTEST build of the fully unrolled

@@ -973,10 +973,13 @@ int launch_infer32_wide(const ActorInferArgs32*, int, int, int, hipStream_t);
     PREFIX template int launch_critic32_ksh<KSHV>(const CriticPhaseArgs32*, int, int, int, int, hipStream_t);  \
     PREFIX template int launch_actor32_ksh<KSHV>(const ActorPhaseArgs32*, int, int, int, int, hipStream_t);   \
     PREFIX template int launch_infer32_ksh<KSHV>(const ActorInferArgs32*, int, int, int, int, hipStream_t);
+// Hidden widths with compile-time 4x4x1 kernels, as chunks of 32 (KSH = ceil(width / 32)): 400, 128 / 100, 256, and the
+// other sizes people use (64, 200, 300, 512); one object each (build.py::FUSED_PARTS).  Any other width runs the
+// run-time-width 16x16x4 kernels.
+#define D4PG_KSH_LIST(X) X(13) X(4) X(8) X(2) X(7) X(10) X(16)
 #if D4PG_KSH_PART == -1          // main unit: the widths live in their own objects
-D4PG_PHASE32_INSTANCES(extern, 13)
-D4PG_PHASE32_INSTANCES(extern, 4)
-D4PG_PHASE32_INSTANCES(extern, 8)
+#define D4PG_EXTERN_INSTANCE(K) D4PG_PHASE32_INSTANCES(extern, K)
+D4PG_KSH_LIST(D4PG_EXTERN_INSTANCE)
 #elif D4PG_KSH_PART != 99 && D4PG_KSH_PART != 0        // the unit of one width
 D4PG_PHASE32_INSTANCES(, D4PG_KSH_PART)
 #endif
@@ -1027,11 +1030,21 @@ static int n_warmers32(const PhaseDims& d, int M) {
 #define DISPATCH_PHASE32(LAUNCHER, LDSFN)                                                   \
     const int lds = LDSFN(d, M, mt);                                                        \
     const int grid = d.B / M + extra_blocks;                                                \
-    if (ksh == 13) return LAUNCHER<13>(a, mt, ksn, grid, lds, stream);                      \
-    if (ksh == 4) return LAUNCHER<4>(a, mt, ksn, grid, lds, stream);                        \
-    if (ksh == 8) return LAUNCHER<8>(a, mt, ksn, grid, lds, stream);                        \
+    D4PG_KSH_LIST(D4PG_DISPATCH_ONE_##LAUNCHER)                                             \
     return -10;
+#define D4PG_DISPATCH_ONE_launch_critic32_ksh(K) if (ksh == K) return launch_critic32_ksh<K>(a, mt, ksn, grid, lds, stream);
+#define D4PG_DISPATCH_ONE_launch_actor32_ksh(K) if (ksh == K) return launch_actor32_ksh<K>(a, mt, ksn, grid, lds, stream);
+#define D4PG_DISPATCH_ONE_launch_infer32_ksh(K) if (ksh == K) return launch_infer32_ksh<K>(a, mt, ksn, grid, lds, stream);
 #endif
+D4PG_API int d4pg_phase32_has_width(int ksh) {
+#ifndef D4PG_STAMPS
+#define D4PG_HAS_ONE(K) if (ksh == K) return 1;
+    D4PG_KSH_LIST(D4PG_HAS_ONE)
+    return 0;
+#else
+    return ksh == 13;
+#endif
+}
 
 D4PG_API int d4pg_critic_phase32(const CriticPhaseArgs32* a, int mt, hipStream_t stream) {
     const PhaseDims& d = a->d;
@@ -1114,9 +1127,7 @@ D4PG_API int d4pg_actor_infer32(const ActorInferArgs32* a, int mt, hipStream_t s
     if (ksh == 13) return launch_infer32_ksh<13>(a, mt, ksn, grid, lds, stream);
     return -10;
 #else
-    if (ksh == 13) return launch_infer32_ksh<13>(a, mt, ksn, grid, lds, stream);
-    if (ksh == 4) return launch_infer32_ksh<4>(a, mt, ksn, grid, lds, stream);
-    if (ksh == 8) return launch_infer32_ksh<8>(a, mt, ksn, grid, lds, stream);
+    D4PG_KSH_LIST(D4PG_DISPATCH_ONE_launch_infer32_ksh)
     return -10;
 #endif
 }

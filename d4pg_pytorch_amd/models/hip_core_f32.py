@@ -31,7 +31,6 @@ from .hip_core_bf16 import LDS_LIMIT, HipCoreBf16, ShapeLimit
 from .nets import LayerSlot, Packed32, Shadow32Layout, Shadow32Slot, pad16, pad32, refresh_shadows32
 
 LDS_PAD32 = 4
-SUPPORTED_HIDDEN_CHUNKS = (4, 8, 13)      # 4-row-tile phase kernels exist for hidden widths of 97..128, 225..256, 385..416
 #: batch size from which the 16x16x4 kernels (``csrc/mlp16_dev.h``, tiles of 16 rows) replace the 4x4x1 ones for the
 #: compiled widths (other widths always take them).  Measured, us per update, 4x4x1 / 16x16x4: Walker2d shape batch 1024
 #: 107 / 144, 2048 145 / 158 (128 tiles of 16 rows leave half the chip to the short roles of each launch), 4096
@@ -53,7 +52,9 @@ class HipCoreF32(HipCoreBf16):
         B, S, A, Hd, NO = self.B, self.S, self.A, self.Hd, self.NO
         waves = H.lib().d4pg_phase32_waves()
         ksh = pad32(Hd) // 32
-        narrow_ok = ksh in SUPPORTED_HIDDEN_CHUNKS and (Hd + 63) // 64 <= waves and pad32(S + A) <= 128
+        # 4-row-tile kernels are compiled per hidden-width class of 32 (D4PG_KSH_LIST in csrc/fused32.hip: 64, 100 / 128,
+        # 200, 256, 300, 400, 512); one 64-column tile per wave
+        narrow_ok = bool(H.lib().d4pg_phase32_has_width(ksh)) and (Hd + 63) // 64 <= waves and pad32(S + A) <= 128
         if NO > 64 or A > 64:
             raise ShapeLimit("the fused fp32 pipeline needs <= 64 atoms and <= 64 actions")
         # Two sets of phase kernels.  4x4x1 MFMA on tiles of 4 / 8 / 16 rows, one compiled instance per hidden width
@@ -67,8 +68,8 @@ class HipCoreF32(HipCoreBf16):
         else:
             self.wide = mfma == "16x16"
         if not self.wide and not narrow_ok:
-            raise ShapeLimit(f"dense_size={Hd}: the 4x4x1 phase kernels are built for hidden widths "
-                             f"{[f'{32 * k - 31}..{32 * k}' for k in SUPPORTED_HIDDEN_CHUNKS]}")
+            raise ShapeLimit(f"dense_size={Hd}: no 4x4x1 phase kernels are compiled for this hidden width "
+                             f"(D4PG_KSH_LIST in csrc/fused32.hip); phase_mfma: auto runs the 16x16x4 kernels")
         if B % (8 if self.wide else 4):
             raise ShapeLimit(f"the fused fp32 pipeline needs batch_size to be a multiple of {8 if self.wide else 4}")
         if self.wide:

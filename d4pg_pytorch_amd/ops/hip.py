@@ -484,6 +484,8 @@ def lib() -> C.CDLL:
         if _lib.d4pg_devstate_size() != C.sizeof(DevStateMirror):
             raise RuntimeError("DevState layout mismatch between csrc/common.h and ops/hip.py")
         _lib.d4pg_phase32_waves.restype = C.c_int
+        _lib.d4pg_phase32_has_width.restype = C.c_int
+        _lib.d4pg_phase32_has_width.argtypes = [C.c_int]
         check_struct_sizes(_lib)
     return _lib
 

@@ -39,11 +39,12 @@ def test_hbm_topology_trains_on_the_gpu(tmp_path, model, per):
     assert glob.glob(os.path.join(exp, "agent_0", "local_episode_*_reward_*.pt"))
 
 
-@pytest.mark.parametrize("width", [300, 64])
+@pytest.mark.parametrize("width", [300, 72])
 def test_any_hidden_width_runs_the_fused_kernels_through_the_whole_topology(tmp_path, width):
     """The reference takes any ``dense_size`` (models/d4pg/networks.py:10,23-25; its own test file uses 100).  Widths
-    outside the compile-time classes run the 16x16x4 kernels: learner (graph, PER through the HBM replay), GPU
-    exploiter with single-launch inference and device explorers, end to end."""
+    with compile-time 4x4x1 kernels (300) and widths without (72: the run-time-width 16x16x4 kernels) both run the
+    fused pipeline: learner (graph, PER through the HBM replay), GPU exploiter with single-launch inference and device
+    explorers, end to end."""
     from d4pg_pytorch_amd.actors.gpu_actor import GpuActor
     from d4pg_pytorch_amd.models.core import build_core
     cfg = dict(env="Pendulum-v0", model="d4pg", num_agents=2, batch_size=128, num_steps_train=600,
@@ -52,7 +53,7 @@ def test_any_hidden_width_runs_the_fused_kernels_through_the_whole_topology(tmp_
                envs_per_agent=4, gpu_rollout_envs=32, gpu_rollout_segment=32, num_episode_save=1000,
                results_path=str(tmp_path / "results"))
     core = build_core(default_config(**{k: v for k, v in cfg.items() if k != "results_path"}), "cuda")
-    assert type(core).__name__ == "HipCoreF32" and core.wide
+    assert type(core).__name__ == "HipCoreF32" and core.wide == (width == 72)
     assert GpuActor(3, 1, width, max_batch=8).launches_per_act == 1
     del core
     engine = load_engine(cfg)
