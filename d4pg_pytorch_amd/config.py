@@ -122,6 +122,7 @@ EXTENSION_DEFAULTS: Dict[str, Any] = {
     "ingest_interval": 32,           # learner updates between two drains of the explorer rings
     "ring_dma": True,                # DMA rows straight out of the explorers' shared-memory rings (registered with the
                                      # HIP runtime); False: pop into a pinned staging buffer first
+    "dp_optimizer": "tiles",         # gradient-exchange mode: "tiles" = the weight-gradient kernel applies the summed gradients tile by tile, "flat" = the element-wise optimiser kernel (csrc/optim.hip)
     "phase_mfma": "auto",            # fp32 phase kernels: "auto" | "4x4" (v_mfma_f32_4x4x1, compiled widths) | "16x16" (v_mfma_f32_16x16x4, any width)
     "phase_tile_rows": "auto",       # batch rows per phase workgroup: "auto" | 4 | 8 | 16 (fp32) | 16 | 32 (bf16)
     "sample_ahead": 32,              # uniform replay, fused pipelines: batches drawn per sampling launch = updates per

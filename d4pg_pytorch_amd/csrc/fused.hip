@@ -1229,7 +1229,8 @@ struct WgradGroup {
     WgradDesc p[WG_MAX];
     int count, total_tiles;
     int Bp;             // K: batch rows rounded up to a multiple of 32
-    int pad_;
+    int apply_only;     // gradient-exchange mode: the (all-reduced) gradients are in C / rowsum already, every tile only
+                        // applies them: Adam, Polyak, shadows, with the tile-shaped stores of the fused optimiser
     WgradAdam opt;
     // Prioritised replay: the batch of the NEXT update is drawn by extra workgroups of the finishing
     // launch (one wave per row), where it sees the priorities this update has just written back (the
@@ -1321,8 +1322,9 @@ __global__ __launch_bounds__(64 * NWV) void wgrad_kernel(const WgradGroup g) {
     const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
     // the bias gradient (row sums of dY) is only needed from the first tile column
     const bool want_rowsum = d.rowsum != nullptr && tn == 0;
+    const bool apply_only = g.apply_only != 0;      // (uniform over the launch)
 #pragma unroll 8
-    for (int ks = k0; ks < k1; ++ks) {
+    for (int ks = apply_only ? k1 : k0; ks < k1; ++ks) {
         bf16x8 av = *reinterpret_cast<const bf16x8*>(arow + ks * 512);
         bf16x8 bv = *reinterpret_cast<const bf16x8*>(brow + ks * 512);
         av = m_ok ? av : zero;
@@ -1334,13 +1336,15 @@ __global__ __launch_bounds__(64 * NWV) void wgrad_kernel(const WgradGroup g) {
         }
     }
     STAMP(1, 22);
+    if (!apply_only) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) red[(wave * 16 + i) * 64 + lane] = acc[i];
-    if (want_rowsum) {
-        asum += __shfl_xor(asum, 32, 64);
-        if (lane < 32) cs[wave * 32 + lane] = asum;
+        for (int i = 0; i < 16; ++i) red[(wave * 16 + i) * 64 + lane] = acc[i];
+        if (want_rowsum) {
+            asum += __shfl_xor(asum, 32, 64);
+            if (lane < 32) cs[wave * 32 + lane] = asum;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     STAMP(1, 23);
     {
         if (fuse) {
@@ -1353,9 +1357,13 @@ __global__ __launch_bounds__(64 * NWV) void wgrad_kernel(const WgradGroup g) {
         for (int i = 0; i < EPT; ++i) {
             const int reg = wave * EPT + i;
             float gv = 0.f;
-#pragma unroll
-            for (int w = 0; w < NWV; ++w) gv += red[(w * 16 + reg) * 64 + lane];
             const int cm = row_of_reg(reg);
+            if (!apply_only) {
+#pragma unroll
+                for (int w = 0; w < NWV; ++w) gv += red[(w * 16 + reg) * 64 + lane];
+            } else if (cm < d.M && cn < d.N) {
+                gv = d.C[(size_t)cm * d.ldc + cn];
+            }
             pnew[i] = 0.f;
             if (cm < d.M && cn < d.N) {
                 // the gradient itself goes to memory only when something outside reads it (the all-reduce of
@@ -1403,8 +1411,12 @@ __global__ __launch_bounds__(64 * NWV) void wgrad_kernel(const WgradGroup g) {
             const int cm = tm * 32 + threadIdx.x;
             if (cm < d.M) {
                 float gb = 0.f;
+                if (apply_only) {
+                    gb = d.rowsum[cm];
+                } else {
 #pragma unroll
-                for (int w = 0; w < NWV; ++w) gb += cs[w * 32 + threadIdx.x];
+                    for (int w = 0; w < NWV; ++w) gb += cs[w * 32 + threadIdx.x];
+                }
                 if (!fuse) d.rowsum[cm] = gb;
                 if (fuse) {
                     float tv;
@@ -1450,11 +1462,15 @@ D4PG_API int d4pg_wgrad(WgradGroup* g, hipStream_t stream) {
         base += d.tiles_m * d.tiles_n;
     }
     g->total_tiles = base;
+    if (g->apply_only && g->opt.p == nullptr) return -7;
+    for (int i = 0; g->apply_only && i < g->count; ++i)
+        if (g->p[i].rowsum == nullptr) return -7;
     // waves per workgroup (they split the batch): one k-step of 16 batch rows per wave up to 16 waves;
     // measured on MI355X (us per update, batch 256 / 1024 / 2048): 4 waves 68.0 / 79.2 / 91.8,
     // 8 waves 66.5 / 73.5 / 79.3, 16 waves 66.2 / 70.8 / 74.8.  D4PG_WGRAD_WAVES overrides (tuning).
     int nwv = g->Bp >= 256 ? 16 : (g->Bp >= 128 ? 8 : 4);
-    if (const char* e = getenv("D4PG_WGRAD_WAVES")) nwv = atoi(e);
+    static const int forced_waves = [] { const char* e = getenv("D4PG_WGRAD_WAVES"); return e ? atoi(e) : 0; }();      // (A/B runs)
+    if (forced_waves) nwv = forced_waves;
     if (nwv == 16) return launch_wgrad(wgrad_kernel<16>, 16, base, *g, stream);
     if (nwv == 8) return launch_wgrad(wgrad_kernel<8>, 8, base, *g, stream);
     return launch_wgrad(wgrad_kernel<4>, 4, base, *g, stream);

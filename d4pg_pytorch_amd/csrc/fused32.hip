@@ -1260,6 +1260,12 @@ struct WgradGroup32 {
     int smp_rows;
     int tree_parts;            // > 0: that many more workgroups write the update's priorities into the tree (*tree)
     const TreeUpdateArgs* tree;
+    // Gradient-exchange mode: 1 = the gradients are already in C / rowsum (written by a launch without optimiser, summed
+    // over the ranks by the all-reduce between the two launches); every tile only APPLIES them: Adam, Polyak, packed
+    // copies, with the tile-shaped stores of the fused optimiser (a flat element-wise kernel scatters 4-byte stores over
+    // the packed copies and takes 10 us for a 190 k-parameter network; this launch takes what the epilogue takes).
+    int apply_only;
+    int pad_;
 };
 
 template <int NWV>
@@ -1332,7 +1338,9 @@ __global__ __launch_bounds__(64 * NWV) void wgrad32_kernel(const WgradGroup32 g)
     // last group and are not multiplied.
     constexpr int WG_DEPTH = 4;
     f32x4 avq[WG_DEPTH], bvq[WG_DEPTH];
-    if (g1 - g0 <= 2) {      // (workgroup-uniform) small batches: one or two groups per wave, nothing to pipeline
+    const bool apply_only = g.apply_only != 0;      // (uniform over the launch)
+    if (apply_only) {
+    } else if (g1 - g0 <= 2) {      // (workgroup-uniform) small batches: one or two groups per wave, nothing to pipeline
         for (int gi = g0; gi < g1; ++gi) {
             f32x4 av = *reinterpret_cast<const f32x4*>(arow + gi * 256);
             f32x4 bv = *reinterpret_cast<const f32x4*>(brow + gi * 256);
@@ -1370,13 +1378,15 @@ __global__ __launch_bounds__(64 * NWV) void wgrad32_kernel(const WgradGroup32 g)
             }
         }
     }
+    if (!apply_only) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) red[(wave * 16 + i) * 64 + lane] = acc[i];
-    if (want_rowsum) {
-        asum += __shfl_xor(asum, 32, 64);
-        if (lane < 32) cs[wave * 32 + lane] = asum;
+        for (int i = 0; i < 16; ++i) red[(wave * 16 + i) * 64 + lane] = acc[i];
+        if (want_rowsum) {
+            asum += __shfl_xor(asum, 32, 64);
+            if (lane < 32) cs[wave * 32 + lane] = asum;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     if (fuse) {
         step_size = o.lr / step_size;
         inv_sqrt_bc2 = 1.f / sqrtf(inv_sqrt_bc2);
@@ -1388,9 +1398,13 @@ __global__ __launch_bounds__(64 * NWV) void wgrad32_kernel(const WgradGroup32 g)
     for (int i = 0; i < EPT; ++i) {
         const int reg = wave * EPT + i;
         float gv = 0.f;
-#pragma unroll
-        for (int w = 0; w < NWV; ++w) gv += red[(w * 16 + reg) * 64 + lane];
         const int cm = row_of_reg(reg);
+        if (!apply_only) {
+#pragma unroll
+            for (int w = 0; w < NWV; ++w) gv += red[(w * 16 + reg) * 64 + lane];
+        } else if (cm < d.M && cn < d.N) {
+            gv = d.C[(size_t)cm * d.ldc + cn];
+        }
         if (cm < d.M && cn < d.N) {
             if (!fuse) {
                 d.C[(size_t)cm * d.ldc + cn] = gv;       // read by the gradient all-reduce
@@ -1411,8 +1425,12 @@ __global__ __launch_bounds__(64 * NWV) void wgrad32_kernel(const WgradGroup32 g)
         const int cm = tm * 32 + threadIdx.x;
         if (cm < d.M) {
             float gb = 0.f;
+            if (apply_only) {
+                gb = d.rowsum[cm];
+            } else {
 #pragma unroll
-            for (int w = 0; w < NWV; ++w) gb += cs[w * 32 + threadIdx.x];
+                for (int w = 0; w < NWV; ++w) gb += cs[w * 32 + threadIdx.x];
+            }
             if (!fuse) d.rowsum[cm] = gb;
             if (fuse) {
                 float tv;
@@ -1455,6 +1473,9 @@ D4PG_API int d4pg_wgrad32(WgradGroup32* g, hipStream_t stream) {
         base += d.tiles_m * d.tiles_n;
     }
     g->total_tiles = base;
+    if (g->apply_only && g->opt.p == nullptr) return -7;
+    for (int i = 0; g->apply_only && i < g->count; ++i)
+        if (g->p[i].rowsum == nullptr) return -7;
     int nwv = g->Bp >= 128 ? 16 : (g->Bp >= 64 ? 8 : 4);     // one group of 8 batch rows per wave up to 16 waves
     static const int forced_waves = [] { const char* e = getenv("D4PG_WGRAD_WAVES"); return e ? atoi(e) : 0; }();      // (A/B runs)
     if (forced_waves) nwv = forced_waves;

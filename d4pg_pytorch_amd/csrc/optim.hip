@@ -38,6 +38,9 @@ struct ShadowArgs {
     int f32;
 };
 
+// One wavefront per workgroup: a 190 k-parameter network is then 730 workgroups over the 256 CUs (with 256 threads it is
+// 182, fewer than CUs, and the kernel is nothing but memory latency).
+constexpr int ADAM_BLOCK = 64;
 struct AdamPolyakArgs {
     float* p;          // online parameters   [n]
     const float* g;    // gradients           [n]
@@ -59,52 +62,54 @@ struct AdamPolyakArgs {
     ShadowArgs sh;
 };
 
-// ``t`` is read only where ``has_t``; both by value, so that neither vector is forced into scratch memory for its address
-__device__ __forceinline__ void write_shadows(const ShadowArgs& sh, long long e, const f32x4 p, const f32x4 t, const bool has_t) {
+// ``t`` is read only where ``has_t``; both by value, so that neither vector is forced into scratch memory for its address.
+// 32-bit index arithmetic (a network has far fewer than 2^31 parameters; 64-bit division costs hundreds of instructions).
+__device__ __forceinline__ void write_shadows(const ShadowArgs& sh, long long e64, const f32x4 p, const f32x4 t, const bool has_t) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         if (j >= sh.count) break;
         const ShadowMat& m = sh.m[j];
-        const long long rel = e - m.w_off;
-        if (rel < 0 || rel >= (long long)m.out_dim * m.ld) continue;
-        const int o = (int)(rel / m.ld), i0 = (int)(rel - (long long)o * m.ld);   // 4 elements share row o
+        const long long rel64 = e64 - m.w_off;
+        if (rel64 < 0 || rel64 >= (long long)m.out_dim * m.ld) continue;
+        const unsigned rel = (unsigned)rel64, ld = (unsigned)m.ld;
+        const int o = (int)(rel / ld), i0 = (int)(rel - (unsigned)o * ld);   // 4 elements share row o
+        float* const ps32 = (float*)sh.p_shadow;
+        float* const ts32 = (sh.t_shadow != nullptr && has_t) ? (float*)sh.t_shadow : nullptr;
+        __bf16* const ps16 = (__bf16*)sh.p_shadow;
+        __bf16* const ts16 = (sh.t_shadow != nullptr && has_t) ? (__bf16*)sh.t_shadow : nullptr;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int i = i0 + k;
             if (i >= m.in_dim) continue;
-            if (sh.f32) {      // 1: packed32_off (csrc/mlp32_dev.h), 2: packed16_off (csrc/mlp16_dev.h); f_ld / b_ld = padded K
-                float* ps = (float*)sh.p_shadow;
-                if (sh.f32 == 2) {
-                    if (m.f_off >= 0) {
-                        const long long so = m.f_off + packed16_off(o, i, m.f_ld >> 4);
-                        ps[so] = p[k];
-                        if (sh.t_shadow != nullptr && has_t) ((float*)sh.t_shadow)[so] = t[k];
-                    }
-                    if (m.b_off >= 0 && i >= m.b_c0 && i < m.b_c1) ps[m.b_off + packed16_off(i - m.b_c0, o, m.b_ld >> 4)] = p[k];
-                    continue;
+            const bool back = m.b_off >= 0 && i >= m.b_c0 && i < m.b_c1;
+            if (sh.f32 == 2) {             // packed16_off (csrc/mlp16_dev.h); f_ld / b_ld = padded K
+                if (m.f_off >= 0) {
+                    const long long so = m.f_off + packed16_off(o, i, m.f_ld >> 4);
+                    ps32[so] = p[k];
+                    if (ts32 != nullptr) ts32[so] = t[k];
                 }
+                if (back) ps32[m.b_off + packed16_off(i - m.b_c0, o, m.b_ld >> 4)] = p[k];
+            } else if (sh.f32) {           // packed32_off (csrc/mlp32_dev.h)
                 if (m.f_off >= 0) {
                     const long long so = m.f_off + packed32_off(o, i, m.f_ld >> 5);
-                    ps[so] = p[k];
-                    if (sh.t_shadow != nullptr && has_t) ((float*)sh.t_shadow)[so] = t[k];
+                    ps32[so] = p[k];
+                    if (ts32 != nullptr) ts32[so] = t[k];
                 }
-                if (m.b_off >= 0 && i >= m.b_c0 && i < m.b_c1) ps[m.b_off + packed32_off(i - m.b_c0, o, m.b_ld >> 5)] = p[k];
-                continue;
+                if (back) ps32[m.b_off + packed32_off(i - m.b_c0, o, m.b_ld >> 5)] = p[k];
+            } else {                       // bf16 copies (csrc/common.h::packed_off)
+                if (m.f_off >= 0) {
+                    const long long so = m.f_off + packed_off(o, i, m.f_ld >> 5);
+                    ps16[so] = (__bf16)p[k];
+                    if (ts16 != nullptr) ts16[so] = (__bf16)t[k];
+                }
+                if (back) ps16[m.b_off + packed_off(i - m.b_c0, o, m.b_ld >> 5)] = (__bf16)p[k];
             }
-            __bf16* ps = (__bf16*)sh.p_shadow;
-            if (m.f_off >= 0) {
-                const long long so = m.f_off + packed_off(o, i, m.f_ld >> 5);
-                ps[so] = (__bf16)p[k];
-                if (sh.t_shadow != nullptr && has_t) ((__bf16*)sh.t_shadow)[so] = (__bf16)t[k];
-            }
-            if (m.b_off >= 0 && i >= m.b_c0 && i < m.b_c1)
-                ps[m.b_off + packed_off(i - m.b_c0, o, m.b_ld >> 5)] = (__bf16)p[k];
         }
         break;
     }
 }
 
-__global__ __launch_bounds__(256) void adam_polyak_kernel(const AdamPolyakArgs a) {
+__global__ __launch_bounds__(ADAM_BLOCK) void adam_polyak_kernel(const AdamPolyakArgs a) {
     const float bc1 = a.st->bc1, bc2 = a.st->bc2;
     const float step_size = a.lr / bc1;
     const float inv_sqrt_bc2 = 1.f / sqrtf(bc2);
@@ -133,7 +138,6 @@ __global__ __launch_bounds__(256) void adam_polyak_kernel(const AdamPolyakArgs a
     if (a.finish_step && blockIdx.x == 0) {
         if (a.metrics != nullptr) {
             // block 0 folds this update's losses into the running metric sums
-            __shared__ float red[2][4];
             float vl = 0.f, pl = 0.f;
             for (int b = threadIdx.x; b < a.B; b += blockDim.x) {
                 vl += a.per_loss[b] * (a.weights ? a.weights[b] : 1.f);
@@ -141,14 +145,9 @@ __global__ __launch_bounds__(256) void adam_polyak_kernel(const AdamPolyakArgs a
             }
             vl = wave_sum(vl);
             pl = wave_sum(pl);
-            if ((threadIdx.x & 63) == 0) {
-                red[0][threadIdx.x >> 6] = vl;
-                red[1][threadIdx.x >> 6] = pl;
-            }
-            __syncthreads();
             if (threadIdx.x == 0) {
-                a.metrics[MET_VALUE_LOSS] += (red[0][0] + red[0][1] + red[0][2] + red[0][3]) * a.inv_B;
-                a.metrics[MET_POLICY_LOSS] += (red[1][0] + red[1][1] + red[1][2] + red[1][3]) * a.inv_B;
+                a.metrics[MET_VALUE_LOSS] += vl * a.inv_B;
+                a.metrics[MET_POLICY_LOSS] += pl * a.inv_B;
                 a.metrics[MET_COUNT] += 1.f;
             }
         }
@@ -160,9 +159,9 @@ D4PG_API int d4pg_adam_polyak(const AdamPolyakArgs* a, hipStream_t stream) {
     if (a->n < 4 || (a->n & 3)) return -1;
     if (((uintptr_t)a->p | (uintptr_t)a->g | (uintptr_t)a->m | (uintptr_t)a->v | (uintptr_t)a->t) & 15) return -2;
     const long long n4 = a->n >> 2;
-    int blocks = (int)((n4 + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(adam_polyak_kernel, dim3(blocks), dim3(256), 0, stream, *a);
+    int blocks = (int)((n4 + ADAM_BLOCK - 1) / ADAM_BLOCK);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(adam_polyak_kernel, dim3(blocks), dim3(ADAM_BLOCK), 0, stream, *a);
     return (int)hipGetLastError();
 }
 

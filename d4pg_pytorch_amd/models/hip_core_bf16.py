@@ -48,6 +48,9 @@ class HipCoreBf16(HipCore):
     #: prioritised replay: the actor-phase launch can also draw the next batch (behind its own tree update) and
     #: make the online critic's forward pass on it (``CriticAhead`` mode 3, csrc/fused32.hip)
     supports_per_ahead = False
+    #: gradient-exchange mode: apply the summed gradients with a tile-shaped launch of the weight-gradient kernel
+    #: (``apply_only``) instead of the flat element-wise optimiser kernel
+    supports_apply_only = True
 
     def __init__(self, cfg: Dict, device="cuda", seed: Optional[int] = None):
         super().__init__(cfg, device, seed)
@@ -267,9 +270,10 @@ class HipCoreBf16(HipCore):
             L.ks, L.ntiles, L.N = sh.b_ld // 32, sh.b_rows // 16, sh.b_c1 - sh.b_c0
         return L
 
-    def _wgrad(self, triples, opt=None, sample_next: bool = False, tree_update=None) -> None:
+    def _wgrad(self, triples, opt=None, sample_next: bool = False, tree_update=None, apply_only: bool = False) -> None:
         """dW/db of up to three layers in one launch.  ``opt=(lr, finish)`` additionally applies
-        Adam + Polyak + the shadow refresh inside the same kernel (no data parallelism only)."""
+        Adam + Polyak + the shadow refresh inside the same kernel.  ``apply_only`` (gradient-exchange mode): the
+        gradients are in ``self.grad`` already (a launch without ``opt``, then the all-reduce); the tiles apply them."""
 
         g = H.WgradGroup()
         for i, (dyT, xT, slot, sh) in enumerate(triples):
@@ -281,7 +285,7 @@ class HipCoreBf16(HipCore):
             d.w_off, d.b_off = slot.w_off, slot.b_off
             d.sf_off, d.sb_off = sh.f_off, sh.b_off
             d.sf_ld, d.sb_ld, d.sb_c0, d.sb_c1 = sh.f_ld, sh.b_ld, sh.b_c0, sh.b_c1
-        g.count, g.Bp = len(triples), self.Bp
+        g.count, g.Bp, g.apply_only = len(triples), self.Bp, int(apply_only)
         if opt is not None:
             lr, finish = opt
             o = g.opt
@@ -331,6 +335,7 @@ class HipCoreBf16(HipCore):
         b1, b2 = self.betas
         dims = self.dims
         fuse_opt = self.grad_sync is None
+        apply_tiles = self.supports_apply_only and str(cfg.get("dp_optimizer", "tiles")) != "flat"
 
         def adam_args(net: NetLayout, slots, lr: float, finish: int) -> H.AdamPolyakArgs:
             a = H.AdamPolyakArgs()
@@ -410,13 +415,20 @@ class HipCoreBf16(HipCore):
             ah.h1, ah.h2, ah.lg = self.gc_h1.data_ptr(), self.gc_h2.data_ptr(), self.gc_lg.data_ptr()
             H._check(getattr(H.lib(), self._fn_critic)(a, self.mt, H.stream_ptr()), self._fn_critic)
             # the priority write-back rides along with the actor phase (seg_actor)
-            self._wgrad([(self.c_dlT, self.c_h2T, cl[2], sl.critic[2]), (self.c_dh2T, self.c_h1T, cl[1], sl.critic[1]),
-                         (self.c_dh1T, self.saT, cl[0], sl.critic[0])],
+            self._wgrad(critic_triples,
                         opt=(self.lr_critic, False) if fuse_opt else None, tree_update=tree_dev)
 
+        critic_triples = [(self.c_dlT, self.c_h2T, cl[2], sl.critic[2]), (self.c_dh2T, self.c_h1T, cl[1], sl.critic[1]),
+                          (self.c_dh1T, self.saT, cl[0], sl.critic[0])]
+        actor_triples = [(self.a_daT, self.a_h2T, al[2], sl.actor[2]), (self.a_dh2T, self.a_h1T, al[1], sl.actor[1]),
+                         (self.a_dh1T, self.sT, al[0], sl.actor[0])]
+
         def seg_actor() -> None:
-            if not fuse_opt:
-                H.launch("d4pg_adam_polyak", adam_args(lay.critic, sl.critic, self.lr_critic, 0))
+            if not fuse_opt:       # the critic's gradients are summed over the ranks by now: apply them
+                if apply_tiles:
+                    self._wgrad(critic_triples, opt=(self.lr_critic, False), apply_only=True)
+                else:
+                    H.launch("d4pg_adam_polyak", adam_args(lay.critic, sl.critic, self.lr_critic, 0))
             a = self._actor_args_cls()
             a.d = dims
             a.g_xin, a.g_h1, a.g_h2 = self.g_xin.data_ptr(), self.g_h1.data_ptr(), self.g_h2.data_ptr()
@@ -449,13 +461,15 @@ class HipCoreBf16(HipCore):
                 ah.mode = 3
                 ah.h1, ah.h2, ah.lg = self.gc_h1.data_ptr(), self.gc_h2.data_ptr(), self.gc_lg.data_ptr()
             H._check(getattr(H.lib(), self._fn_actor)(a, self.mt, H.stream_ptr()), self._fn_actor)
-            self._wgrad([(self.a_daT, self.a_h2T, al[2], sl.actor[2]), (self.a_dh2T, self.a_h1T, al[1], sl.actor[1]),
-                         (self.a_dh1T, self.sT, al[0], sl.actor[0])],
+            self._wgrad(actor_triples,
                         opt=(self.lr_actor, True) if fuse_opt else None, sample_next=per_role and not per_ahead)
 
         def seg_finish() -> None:
             if not fuse_opt:
-                H.launch("d4pg_adam_polyak", adam_args(lay.actor, sl.actor, self.lr_actor, 1))
+                if apply_tiles:
+                    self._wgrad(actor_triples, opt=(self.lr_actor, True), apply_only=True)
+                else:
+                    H.launch("d4pg_adam_polyak", adam_args(lay.actor, sl.actor, self.lr_actor, 1))
             self._join_fork()
 
         return [seg_critic, seg_actor, seg_finish]

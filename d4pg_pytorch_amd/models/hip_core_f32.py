@@ -156,7 +156,9 @@ class HipCoreF32(HipCoreBf16):
         L.kg = (p.K + 3) // 4 if p.ksplit == 1 else p.nch * 8       # 16-byte k-groups that hold weights
         return L
 
-    def _wgrad(self, triples, opt=None, sample_next: bool = False, tree_update=None) -> None:
+    def _wgrad(self, triples, opt=None, sample_next: bool = False, tree_update=None, apply_only: bool = False) -> None:
+        """``apply_only``: the gradients are in ``self.grad`` already (an earlier launch without ``opt``, then the
+        all-reduce); the tiles apply them (Adam, Polyak, packed copies) instead of computing them."""
         g = H.WgradGroup32()
         for i, (dyT, xT, slot, sh) in enumerate(triples):
             d = g.p[i]
@@ -170,6 +172,7 @@ class HipCoreF32(HipCoreBf16):
             d.sb_ks = sh.b.ks if sh.b is not None else 0
             d.sb_c0, d.sb_c1 = sh.b_c0, sh.b_c1
         g.count, g.Bp, g.wide = len(triples), self.Bp, int(self.wide)
+        g.apply_only = int(apply_only)
         if opt is not None:
             lr, finish = opt
             o = g.opt

@@ -216,7 +216,7 @@ class WgradAdam(C.Structure):
 
 class WgradGroup(C.Structure):
     _fields_ = [("p", WgradDesc * 3), ("count", C.c_int), ("total_tiles", C.c_int), ("Bp", C.c_int),
-                ("pad_", C.c_int), ("opt", WgradAdam), ("smp", vp), ("smp_rows", C.c_int), ("tree_parts", C.c_int),
+                ("apply_only", C.c_int), ("opt", WgradAdam), ("smp", vp), ("smp_rows", C.c_int), ("tree_parts", C.c_int),
                 ("tree", vp)]
 
 
@@ -259,7 +259,7 @@ class WgradDesc32(C.Structure):
 class WgradGroup32(C.Structure):
     _fields_ = [("p", WgradDesc32 * 3), ("count", C.c_int), ("total_tiles", C.c_int), ("Bp", C.c_int),
                 ("wide", C.c_int), ("opt", WgradAdam), ("smp", vp), ("smp_rows", C.c_int), ("tree_parts", C.c_int),
-                ("tree", vp)]
+                ("tree", vp), ("apply_only", C.c_int), ("pad_", C.c_int)]
 
 
 class OuFuse32(C.Structure):

@@ -180,9 +180,10 @@ class TorchDistComm(Comm):
 #: for the GLOBAL batch, and a rank of the gradient-exchange mode for its LOCAL batch.
 UPDATE_US = {"fp32": {256: 78.0, 512: 86.0, 1024: 106.0, 2048: 145.0, 4096: 221.0},
              "bf16": {256: 52.0, 512: 55.0, 1024: 59.0, 2048: 64.0, 4096: 90.0, 8192: 131.0}}
-#: what the gradient-exchange mode costs on top of the update and its two all-reduces (stand-alone optimiser kernels,
-#: gradients through memory): measured over a world of one, 94.7 - 77.8 us (fp32), 68.7 - 52.2 us (bf16)
-EXCHANGE_OVERHEAD_US = {"fp32": 17.0, "bf16": 16.5}
+#: what the gradient-exchange mode costs on top of the update and its two all-reduces (two more launches that apply the
+#: summed gradients, gradients through memory): measured over a world of one, where an in-graph RCCL all-reduce is no
+#: kernel at all (0.2 us in the probe): 85.4 - 77.5 us (fp32), 59.0 - 52.2 us (bf16) (bench.py --dp-selftest)
+EXCHANGE_OVERHEAD_US = {"fp32": 8.0, "bf16": 7.0}
 #: Without a live communicator to time (``resolve_dp_mode`` called with ``allreduce_us=None``): the largest global batch that is
 #: replicated, by precision; an all-reduce of a 0.8 MB gradient bucket is then taken to cost 35 us.
 REPLICATED_MAX_GLOBAL_BATCH = {"fp32": 2048, "bf16": 8192}
@@ -202,9 +203,14 @@ def update_us(batch: int, compute_dtype: str = "fp32") -> float:
 
 
 def probe_allreduce_us(comm: "Comm", numel: int, device, iters: int = 20) -> float:
-    """Time of one sum all-reduce of ``numel`` floats on the LIVE communicator (median of ``iters`` after a warm-up,
-    then the maximum over the ranks, so that every rank decides from the same number).  This is what replaces a
-    guessed xGMI latency in ``dp_mode: auto``."""
+    """Time of one sum all-reduce of ``numel`` floats on the LIVE communicator, the maximum over the ranks so that
+    every rank decides from the same number.  This is what replaces a guessed xGMI latency in ``dp_mode: auto``.
+
+    With RCCL the all-reduces of the gradient exchange are nodes of the update's graph, so that is how they are timed:
+    ``iters`` dependent all-reduces captured as one graph, replayed, device time between two events divided by
+    ``iters`` (no host launch or synchronisation in the number).  Communicators that go through the host (gloo staging,
+    the in-process fake) are timed from the host, median of ``iters``, as the exchange then runs between graph segments.
+    """
     import time
     buf = torch.zeros(int(numel), dtype=torch.float32, device=device)
     cuda = torch.device(device).type == "cuda"
@@ -212,16 +218,44 @@ def probe_allreduce_us(comm: "Comm", numel: int, device, iters: int = 20) -> flo
         comm.all_reduce_sum_(buf)
     if cuda:
         torch.cuda.synchronize(device)
-    times = []
-    for _ in range(iters):
-        comm.barrier()
-        t0 = time.perf_counter()
-        comm.all_reduce_sum_(buf)
-        if cuda:
+    us = None
+    if cuda and isinstance(comm, TorchDistComm) and comm.backend == "nccl" and not os.environ.get("D4PG_DP_SEGMENTED"):
+        try:
+            us = _graph_allreduce_us(comm, buf, device, iters)
+        except Exception:      # capture refused (an RCCL build without graph support): time from the host instead
+            us = None
             torch.cuda.synchronize(device)
-        times.append(time.perf_counter() - t0)
-    times.sort()
-    return comm.all_reduce_max_scalar(times[len(times) // 2] * 1e6)
+    if us is None:
+        times = []
+        for _ in range(iters):
+            comm.barrier()
+            t0 = time.perf_counter()
+            comm.all_reduce_sum_(buf)
+            if cuda:
+                torch.cuda.synchronize(device)
+            times.append(time.perf_counter() - t0)
+        times.sort()
+        us = times[len(times) // 2] * 1e6
+    return comm.all_reduce_max_scalar(us)
+
+
+def _graph_allreduce_us(comm: "Comm", buf: torch.Tensor, device, iters: int) -> float:
+    stream = torch.cuda.Stream(device=device)
+    stream.wait_stream(torch.cuda.current_stream(device))
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(stream):
+        with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
+            for _ in range(iters):
+                comm.all_reduce_sum_(buf)
+        g.replay()                                  # the first replay pays the upload of the executable graph
+        stream.synchronize()
+        comm.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        g.replay()
+        e1.record(stream)
+        stream.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
 
 
 def resolve_dp_mode(mode: str, local_batch: int, world: int, compute_dtype: str = "fp32",

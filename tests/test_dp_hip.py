@@ -110,10 +110,12 @@ def test_rccl_world_one_in_graph_all_reduce_equals_segmented(dtype, monkeypatch)
     comm = TorchDistComm(device=torch.device("cuda", 0), rank=0, world=1)
     outs = {}
     try:
-        for mode in ("in_graph", "segmented"):
+        for mode in ("in_graph", "in_graph_flat", "segmented"):
             if mode == "segmented":
                 monkeypatch.setenv("D4PG_DP_SEGMENTED", "1")
             cfg = _cfg(256, dtype, graph=True, sample_ahead=8)
+            if mode == "in_graph_flat":      # the element-wise optimiser kernel instead of the tile-shaped apply launch
+                cfg["dp_optimizer"] = "flat"
             core = build_core(cfg, "cuda")
             rp = HbmReplay(cfg, "cuda", core.dev_state)
             core.attach_replay(rp)
@@ -128,13 +130,14 @@ def test_rccl_world_one_in_graph_all_reduce_equals_segmented(dtype, monkeypatch)
             while done < 20:
                 done += core.update_from_replay_many(20 - done)
             torch.cuda.synchronize()
-            assert core._sync_in_graph() == (mode == "in_graph")
+            assert core._sync_in_graph() == (mode != "segmented")
             assert core.read_dev_state().step_done == 20
             outs[mode] = (core.online.flat.clone(), core.target.flat.clone())
     finally:
         comm.close()
-    assert torch.equal(outs["in_graph"][0], outs["segmented"][0])
-    assert torch.equal(outs["in_graph"][1], outs["segmented"][1])
+    for other in ("segmented", "in_graph_flat"):
+        assert torch.equal(outs["in_graph"][0], outs[other][0]), other
+        assert torch.equal(outs["in_graph"][1], outs[other][1]), other
 
 
 # --------------------------------------------------------------------------- real RCCL, two GPUs
