@@ -245,6 +245,7 @@ def main() -> None:
         import torch.distributed as dist
         from d4pg_pytorch_amd.parallel.ipc import ControlBlock
         envs, seg = 4096, 32
+        DONE_SLOT = 10                          # a free fixed slot of the control block: workers that have finished
         rcfg = default_config(**{**cfg, "gpu_rollout_envs": envs, "gpu_rollout_segment": seg, "env_backend": "native",
                                  "rollout_devices": list(range(1, world)), "replay_mem_size": 2_000_000,
                                  "num_steps_train": 10 ** 9})
@@ -254,6 +255,8 @@ def main() -> None:
             from d4pg_pytorch_amd.models.learner import WeightPublisher
             from d4pg_pytorch_amd.parallel.hip_ipc import SharedDeviceBuffer, write_handle
             from d4pg_pytorch_amd.parallel.row_mailbox import RowMailbox
+            from d4pg_pytorch_amd.parallel.ipc import cleanup_names
+            cleanup_names([name])               # a segment an earlier, killed run on this port left behind
             ctrl = ControlBlock.create(n_workers=world + 2, name=name)
             core_r = build_core(rcfg, device)
             rp = HbmReplay(rcfg, device, core_r.dev_state)
@@ -286,7 +289,13 @@ def main() -> None:
                    "rollout_workers": world - 1, "rollout_envs_per_worker": envs, "rollout_segment_steps": seg,
                    "rollout_env": env + " (native device simulator)"}
             ctrl.request_stop()
-            dist.barrier()
+            # the workers report in through the control block, polled from Python: a worker that died must not leave
+            # this rank inside a collective it can never leave (the headline of the run is still to be printed)
+            t_end = time.perf_counter() + 30.0
+            while ctrl.load(DONE_SLOT) < world - 1 and time.perf_counter() < t_end:
+                time.sleep(0.01)
+            if ctrl.load(DONE_SLOT) < world - 1:
+                out["rollout_workers_error"] = "%d of %d workers did not report back" % (world - 1 - ctrl.load(DONE_SLOT), world - 1)
             mailbox.close()
             shared.close()
             for suffix in (".hipipc", ".rows.hipipc"):
@@ -302,7 +311,7 @@ def main() -> None:
             try:
                 run_rollout_worker(rcfg, ctrl, rank - 1, dev_index, hb_slot=rank)
             finally:
-                dist.barrier()
+                ctrl.add(DONE_SLOT, 1)
                 ctrl.close()
         return out
 
@@ -553,6 +562,14 @@ def main() -> None:
             if rank == 0:
                 emit(core, dt, dp_mode, metrics_primary)
             os._exit(0)
+
+        def extras_terminated(signum, frame):      # the launcher ends every rank when one of them has died
+            extra["rollout_workers_error"] = "terminated by signal %d while the rollout workers ran" % signum
+            if rank == 0:
+                emit(core, dt, dp_mode, metrics_primary)
+            os._exit(0 if rank == 0 else 1)
+        import signal
+        old_term = signal.signal(signal.SIGTERM, extras_terminated)
         import faulthandler
         limit = float(os.environ.get("D4PG_BENCH_EXTRAS_TIMEOUT_S", "150"))
         dog = threading.Timer(limit, extras_hung)
@@ -566,6 +583,7 @@ def main() -> None:
         finally:
             faulthandler.cancel_dump_traceback_later()
             dog.cancel()
+            signal.signal(signal.SIGTERM, old_term)
     emit(core, dt, dp_mode, metrics_primary)
     comm.close()
 
