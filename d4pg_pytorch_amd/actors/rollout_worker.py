@@ -36,8 +36,9 @@ class _RowShape:
 
 
 def run_rollout_worker(config: Dict, ctrl: ControlBlock, k: int, device_index: int, hb_slot: int,
-                       max_segments: int = 0) -> int:
-    """Body of worker ``k``; returns the environment steps it delivered."""
+                       max_segments: int = 0, stats: Dict = None) -> int:
+    """Body of worker ``k``; returns the environment steps it delivered (``stats``, if given, receives the number of
+    policy refreshes and the last weight version packed)."""
     import torch
     from ..envs.device_envs import make_device_env
     from ..parallel.hip_ipc import SharedDeviceBuffer, read_handle
@@ -77,7 +78,7 @@ def run_rollout_worker(config: Dict, ctrl: ControlBlock, k: int, device_index: i
         raise ValueError("rollout worker and learner disagree on the segment size or the number of workers")
     # the learner's weight slots: [online actor | target actor] x 2, written alternately (WeightPublisher)
     shared, n_actor, version = None, rollout.actor.layout.numel, 0
-    delivered = segments = 0
+    delivered = segments = refreshes = 0
     try:
         while not ctrl.stop and (max_segments <= 0 or segments < max_segments):
             if shared is None:
@@ -108,6 +109,7 @@ def run_rollout_worker(config: Dict, ctrl: ControlBlock, k: int, device_index: i
                             break
                         v = max(v, ctrl.load(ControlBlock.GPU_WEIGHT_VERSION))
                 version = v
+                refreshes += 1
                 note("packed")
             rollout.launch()
             rollout.done_event.synchronize()
@@ -127,6 +129,8 @@ def run_rollout_worker(config: Dict, ctrl: ControlBlock, k: int, device_index: i
                     ctrl.add(ControlBlock.GLOBAL_EPISODE, n_ep)
             beat()
     finally:
+        if stats is not None:
+            stats.update(policy_refreshes=refreshes, last_weight_version=version, segments=segments)
         torch.cuda.synchronize(device)
         mailbox.close()
         if shared is not None:
@@ -138,8 +142,11 @@ def rollout_worker(config: Dict, ctrl_name: str, k: int, device_index: int, hb_s
     """Process entry (spawned by the engine)."""
     ctrl = ControlBlock.attach(ctrl_name)
     try:
-        n = run_rollout_worker(config, ctrl, k, device_index, hb_slot)
-        print(f"Exit rollout worker {k} on cuda:{device_index}: {n} environment steps delivered.", flush=True)
+        stats: Dict = {}
+        n = run_rollout_worker(config, ctrl, k, device_index, hb_slot, stats=stats)
+        print(f"Exit rollout worker {k} on cuda:{device_index}: {n} environment steps delivered in {stats.get('segments')} "
+              f"segments, {stats.get('policy_refreshes')} policy refreshes (last weight version "
+              f"{stats.get('last_weight_version')} of {ctrl.load(ControlBlock.GPU_WEIGHT_VERSION)}).", flush=True)
     except Exception:
         traceback.print_exc()
         raise

@@ -125,7 +125,10 @@ def _hip_units(stamps: bool):
         parts = FUSED_PARTS[name] if (name in FUSED_PARTS and not (stamps and name == "fused.hip")) else (None,)
         for part in parts:
             o = os.path.join(objdir, name + ("" if part is None else f".part{part}") + ".o")
-            cmd = [hipcc, OPT_LEVEL.get(name, "-O3"), f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-c", s, "-o", o]
+            # --offload-compress: the gfx950 code objects are stored compressed in the fat binary (the HIP runtime inflates
+            # them at load): the library shrinks from 15.9 to about 4 MB, which every copy of the tree to a GPU box pays for
+            cmd = [hipcc, OPT_LEVEL.get(name, "-O3"), f"--offload-arch={ARCH}", "--offload-compress", "-fPIC", "-std=c++17",
+                   "-c", s, "-o", o]
             if part is not None:
                 cmd.insert(1, f"-DD4PG_KSH_PART={part}")
             if stamps:

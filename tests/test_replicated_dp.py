@@ -256,11 +256,9 @@ def test_odd_update_counts_replay_power_of_two_runs_and_late_captures_drop_the_a
     assert torch.equal(outs["plain"][0], outs["runs"][0]) and torch.equal(outs["plain"][1], outs["runs"][1])
 
 
-def test_replicated_per_world_two_learns_the_pendulum():
-    """Replicated data parallelism WITH prioritised replay over a world of two, as a learning run: each rank owns a
-    shard of the replay fed by its own device explorers, draws its half of every global batch by priority, and writes
-    back the priorities of its own rows only, one to two chunks after the draw.  Both ranks must hold bit-identical
-    parameters at the end and the greedy target policy must swing the pendulum up (a random policy scores about -1200)."""
+def _replicated_per_pendulum_run(tau: float, updates: int, seed: int = 21, per: int = 1):
+    """Two thread-ranks, replicated mode: each owns a replay shard fed by its own device explorers.  Returns (the two
+    cores, their priority leaves, the greedy return of rank 0's target policy)."""
     from d4pg_pytorch_amd.actors.gpu_rollout import DeviceRollout
     from d4pg_pytorch_amd.envs.device_pendulum import DevicePendulum
     from d4pg_pytorch_amd.models.core import build_core
@@ -268,16 +266,16 @@ def test_replicated_per_world_two_learns_the_pendulum():
     from d4pg_pytorch_amd.parallel.replicated import attach_replicated
     from d4pg_pytorch_amd.replay.hbm_replay import HbmReplay
     from d4pg_pytorch_amd.utils.learning import GreedyEvaluator, pendulum_config
-    world, Bl, updates = 2, 128, 20_000      # the budget of tests/test_learning_gpu.py
-    cfg = pendulum_config("d4pg", "fp32", 21, batch_size=Bl * world, replay_memory_prioritized=1, use_hip_graph=False,
-                          replay_mem_size=200_000)
+    world, Bl = 2, 128
+    cfg = pendulum_config("d4pg", "fp32", seed, batch_size=Bl * world, replay_memory_prioritized=per, use_hip_graph=False,
+                          replay_mem_size=200_000, tau=tau)
     comms = ThreadComm.group(world)
     cores, leaves, errs = [None] * world, [None] * world, []
 
     def run(r):
         try:
             torch.cuda.set_device(0)
-            core = build_core(cfg, "cuda", seed=21 + r)
+            core = build_core(cfg, "cuda", seed=seed + r)
             rp = HbmReplay(cfg, "cuda", core.dev_state)
             ro = DeviceRollout(cfg, DevicePendulum(16, "cuda", seed=50 + r), rp, "cuda", segment=32, seed=60 + r,
                                use_graph=False)
@@ -303,9 +301,18 @@ def test_replicated_per_world_two_learns_the_pendulum():
     [t.start() for t in ts]
     [t.join(600) for t in ts]
     assert not errs, errs
+    ret = GreedyEvaluator(cfg, 64, "cuda", 99)(cores[0].target.flat.data_ptr(), cores[0].layout.actor.base)
+    return cores, leaves, ret
+
+
+def test_replicated_per_world_two_learns_the_pendulum():
+    """Replicated data parallelism WITH prioritised replay over a world of two, as a learning run: each rank owns a
+    shard of the replay fed by its own device explorers, draws its half of every global batch by priority, and writes
+    back the priorities of its own rows only, one to two chunks after the draw.  Both ranks must hold bit-identical
+    parameters at the end and the greedy target policy must swing the pendulum up (a random policy scores about -1200)."""
+    cores, leaves, ret = _replicated_per_pendulum_run(tau=0.001, updates=20_000)
     assert torch.equal(cores[0].online.flat, cores[1].online.flat)
     assert torch.equal(cores[0].target.flat, cores[1].target.flat)
-    for r in range(world):      # priorities were written back on both shards: a spread, not the insert value everywhere
+    for r in range(2):      # priorities were written back on both shards: a spread, not the insert value everywhere
         assert leaves[r].unique().numel() > 1000
-    ret = GreedyEvaluator(cfg, 64, "cuda", 99)(cores[0].target.flat.data_ptr(), cores[0].layout.actor.base)
     assert ret > -400.0, ret
