@@ -205,6 +205,13 @@ class Engine:
         from .replay.hbm_replay import row_ld
         n_actor = NetLayout.build(cfg["state_dim"], cfg["dense_size"], cfg["action_dim"]).numel
         rollout_devices = list(cfg.get("rollout_devices") or []) if str(cfg["device"]).startswith("cuda") else []
+        if rollout_devices:
+            import torch
+            n_gpus = torch.cuda.device_count()          # (counting devices does not initialise the GPU in this process)
+            missing = [d for d in rollout_devices if d >= n_gpus]
+            if missing:
+                raise ValueError(f"rollout_devices {rollout_devices}: this machine has {n_gpus} GPU(s), no cuda:{missing[0]} "
+                                 f"(e.g. --set rollout_devices={list(range(min(1, n_gpus - 1), n_gpus)) or [0]})")
         ctrl = ControlBlock.create(n_workers=world + total_agents + 2 + len(rollout_devices))
         slab = WeightSlab.create(2 * n_actor)
         rings: List[ShmRing] = []

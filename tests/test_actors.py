@@ -108,3 +108,28 @@ def test_cpu_actor_matches_torch_mlp_and_roundtrips_state_dict():
     other = CpuActor(S, A, Hd, action_scale=2.0)
     other.load_state_dict(sd)
     np.testing.assert_allclose(other.act(x), 2.0 * cpu.act(x), rtol=1e-6)
+
+
+def test_step_counter_slots_alternate_and_rewind_to_slot_zero():
+    """The Philox position of a device environment (envs/device_pendulum.py::StepCounter): unpaired, every launch reads
+    and a follow-up launch increments ONE slot; paired, launches alternate between two slots and the environment's own
+    kernel writes the successor, so a captured sequence has to end on the slot it started from."""
+    from types import SimpleNamespace
+
+    from d4pg_pytorch_amd.envs.device_pendulum import StepCounter
+    c = StepCounter("cpu")
+    base = c.slots.data_ptr()
+    a = SimpleNamespace(counter=None, counter_next=None)
+    c.fill(a)
+    assert (a.counter, a.counter_next, c.cur) == (base, None, 0)            # unpaired: in place
+    c.paired = True
+    seen = []
+    for _ in range(4):
+        a = SimpleNamespace(counter=None, counter_next=None)
+        c.fill(a)
+        seen.append((a.counter - base, a.counter_next - base))
+    assert seen == [(0, 8), (8, 0), (0, 8), (8, 0)] and c.cur == 0
+    assert c.ptr == base
+    c.rewind()                                                               # on slot 0 already: no launch, nothing to load
+    c.fill(SimpleNamespace(counter=None, counter_next=None))
+    assert c.cur == 1 and c.ptr == base + 8

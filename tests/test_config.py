@@ -111,3 +111,22 @@ def test_reference_test_config_shape_loads(tmp_path):
     raw.update(env="Pendulum-v0", model="d4pg", state_dim=3, action_dim=1)
     cfg = finalize_config(raw)
     assert cfg["dense_size"] == 100 and cfg["replay_mem_size"] == 1000
+
+
+def test_rollout_worker_config_loads_and_is_checked_against_the_machine():
+    """configs/mi355x/walker2d_d4pg_rollout_workers_8gpu.yml: learner on GPU 0, a rollout worker on each of GPUs 1 - 7; the
+    engine refuses devices the machine does not have before it spawns anything."""
+    import os
+
+    import pytest
+    import torch
+    from d4pg_pytorch_amd.config import read_config
+    from d4pg_pytorch_amd.engine import load_engine
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = read_config(os.path.join(root, "configs", "mi355x", "walker2d_d4pg_rollout_workers_8gpu.yml"))
+    assert cfg["rollout_devices"] == [1, 2, 3, 4, 5, 6, 7] and cfg["gpu_rollout_envs"] == 1024
+    assert read_config(os.path.join(root, "configs", "mi355x", "walker2d_d4pg_rollout_workers_8gpu.yml"),
+                       overrides=["rollout_devices=[2,3]"])["rollout_devices"] == [2, 3]
+    if torch.cuda.device_count() < 8:
+        with pytest.raises(ValueError, match="rollout_devices"):
+            load_engine(dict(cfg, num_steps_train=10, results_path="/tmp/d4pg_never_written")).train()

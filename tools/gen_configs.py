@@ -222,6 +222,27 @@ gpu_rollout_segment: 32   # steps per captured rollout segment
 gpu_rollout_interval: 32  # learner updates between two segments (256 env steps per update)
 num_steps_train: 200000
 """,
+    "walker2d_d4pg_rollout_workers_8gpu.yml": """# Walker2d D4PG on one 8-GPU node: the learner and its HBM replay on GPU 0, a rollout worker PROCESS on each of GPUs 1 - 7
+# (actors/rollout_worker.py).  A worker steps its environments as kernels on its own GPU, packs the online actor
+# straight out of the learner's HIP-IPC weight slots (peer memory over xGMI) and writes every segment's rows into a
+# staging ring in the learner's HBM (parallel/row_mailbox.py); the learner's GPU runs updates only.  The GPU exploiter
+# plays the host simulator with the target policy.  On fewer GPUs: --set rollout_devices=[1,2,3]; [0] runs the worker
+# beside the learner on one GPU.
+env: Walker2d-v2
+model: d4pg
+num_agents: 1             # the exploiter only
+v_min: 0.0
+v_max: 400.0
+device: cuda
+replay_device: hbm
+rollout_devices: [1, 2, 3, 4, 5, 6, 7]
+gpu_rollout_envs: 1024    # environments per worker
+gpu_rollout_segment: 32   # steps per captured rollout segment (two launches per step)
+updates_per_env_step: 0.002        # the learner never waits for data at 7 x 1024 environments; this only bounds it from above
+max_restarts_per_process: 3
+max_restarts_per_hour: 20
+num_steps_train: 200000
+""",
     "bipedal_d4pg_device_explorers.yml": """# BipedalWalker-v2 D4PG with the explorers ON the learner's GPU (the simulator as a kernel, one thread per environment); the
 # GPU exploiter plays the host simulator with the learner's target policy, read through HIP IPC.
 env: BipedalWalker-v2
