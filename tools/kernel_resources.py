@@ -47,9 +47,16 @@ def main():
     with tempfile.TemporaryDirectory() as tmp:
         for obj in sorted(glob.glob(os.path.join(ROOT, "d4pg_pytorch_amd", "csrc", "build", "*.o"))):
             local = os.path.join(tmp, os.path.basename(obj))
-            os.symlink(obj, local)
-            subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", local], capture_output=True, cwd=tmp)
-            for co in glob.glob(local + ".*gfx950"):
+            # the objects hold their gfx950 code compressed (build.py: --offload-compress): take the fat binary section
+            # and let the offload bundler inflate the code object
+            fat, co_path = local + ".fatbin", local + ".gfx950.co"
+            subprocess.run([os.path.join(LLVM, "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", obj, fat],
+                           capture_output=True)
+            if not os.path.exists(fat) or os.path.getsize(fat) == 0:
+                continue
+            subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={fat}",
+                            "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co_path}"], capture_output=True)
+            for co in glob.glob(co_path):
                 notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], capture_output=True, text=True).stdout
                 for block in notes.split("- .agpr_count:")[1:]:
                     block = ".agpr_count:" + block
