@@ -488,9 +488,9 @@ def main() -> None:
             dp_mode = args.dp_mode
             core, dt = run_replicated() if dp_mode == "replicated" else run_grad_allreduce()
         else:
-            # both modes are timed, the one the framework's static rule (dp_mode: auto) would pick first so that
-            # nothing the other run does can affect it; `value` is the faster of the two (a job is free to set
-            # dp_mode), both are reported with the rule's own pick (`dp_mode_auto`)
+            # both modes are timed, the one dp_mode: auto picks on this machine first so that nothing the other run
+            # does can affect it; `value` is that mode's, the faster of the two is reported next to it
+            # (`faster_dp_mode`, `faster_dp_mode_value`: a job is free to set dp_mode)
             import threading
             # what dp_mode: auto picks on THIS machine: the framework times one all-reduce of the critic's gradient
             # bucket on the live communicator (parallel/comm.py::probe_allreduce_us) and compares the two modes' costs
@@ -501,6 +501,8 @@ def main() -> None:
                 ar_us = probe_allreduce_us(comm, bucket, device)
                 extra["allreduce_probe_us"] = round(ar_us, 2)
                 extra["allreduce_probe_bytes"] = bucket * 4
+                if args.dp_selftest:      # a world of one: RCCL launches nothing, the captured form is known to run
+                    extra["allreduce_probe_us_in_graph"] = round(probe_allreduce_us(comm, bucket, device, in_graph=True), 2)
             except Exception as exc:
                 ar_us = None
                 extra["allreduce_probe_error"] = repr(exc)[:200]
@@ -576,6 +578,14 @@ def main() -> None:
         dog.daemon = True
         dog.start()
         faulthandler.dump_traceback_later(max(1.0, limit - 5.0), exit=False)     # a hang names its own stack on stderr
+        try:
+            if getattr(comm, "backend", "") == "nccl" and "allreduce_probe_bytes" in extra:
+                # the same all-reduce timed as nodes of a graph (the way the gradient exchange runs it), for the record
+                from d4pg_pytorch_amd.parallel.comm import probe_allreduce_us
+                extra["allreduce_probe_us_in_graph"] = round(
+                    probe_allreduce_us(comm, extra["allreduce_probe_bytes"] // 4, device, in_graph=True), 2)
+        except Exception as exc:
+            extra["allreduce_probe_in_graph_error"] = repr(exc)[:200]
         try:
             extra.update(rollout_workers_extra())
         except Exception as exc:

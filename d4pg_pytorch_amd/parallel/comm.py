@@ -202,14 +202,17 @@ def update_us(batch: int, compute_dtype: str = "fp32") -> float:
     return tab[xs[-1]] * batch / xs[-1]
 
 
-def probe_allreduce_us(comm: "Comm", numel: int, device, iters: int = 20) -> float:
+def probe_allreduce_us(comm: "Comm", numel: int, device, iters: int = 20, in_graph: bool = False) -> float:
     """Time of one sum all-reduce of ``numel`` floats on the LIVE communicator, the maximum over the ranks so that
     every rank decides from the same number.  This is what replaces a guessed xGMI latency in ``dp_mode: auto``.
 
-    With RCCL the all-reduces of the gradient exchange are nodes of the update's graph, so that is how they are timed:
-    ``iters`` dependent all-reduces captured as one graph, replayed, device time between two events divided by
-    ``iters`` (no host launch or synchronisation in the number).  Communicators that go through the host (gloo staging,
-    the in-process fake) are timed from the host, median of ``iters``, as the exchange then runs between graph segments.
+    Default: from the host, the way every other collective of the job is issued — median of ``iters`` (barrier,
+    all-reduce, synchronise), MINUS the median of the same sequence around a one-element device operation, i.e. minus
+    what launching and waiting costs by itself (15 - 20 us): what is left is what the collective adds to a stream.
+    ``in_graph=True`` (RCCL only): ``iters`` dependent all-reduces captured as one graph and replayed, device time
+    between two events — the way the gradient exchange runs them; 0.2 us at a world of one, where RCCL launches nothing.
+    (Not the default: a communicator that cannot run captured collectives would hang the probe, and the probe runs
+    before anything else has been measured; ``bench.py`` records it later, under its watchdog.)
     """
     import time
     buf = torch.zeros(int(numel), dtype=torch.float32, device=device)
@@ -219,23 +222,29 @@ def probe_allreduce_us(comm: "Comm", numel: int, device, iters: int = 20) -> flo
     if cuda:
         torch.cuda.synchronize(device)
     us = None
-    if cuda and isinstance(comm, TorchDistComm) and comm.backend == "nccl" and not os.environ.get("D4PG_DP_SEGMENTED"):
+    if in_graph and cuda and isinstance(comm, TorchDistComm) and comm.backend == "nccl":
         try:
             us = _graph_allreduce_us(comm, buf, device, iters)
         except Exception:      # capture refused (an RCCL build without graph support): time from the host instead
             us = None
             torch.cuda.synchronize(device)
     if us is None:
-        times = []
-        for _ in range(iters):
-            comm.barrier()
-            t0 = time.perf_counter()
-            comm.all_reduce_sum_(buf)
-            if cuda:
-                torch.cuda.synchronize(device)
-            times.append(time.perf_counter() - t0)
-        times.sort()
-        us = times[len(times) // 2] * 1e6
+        one = torch.zeros(1, dtype=torch.float32, device=device)
+
+        def median_us(op) -> float:
+            times = []
+            for _ in range(iters):
+                comm.barrier()
+                t0 = time.perf_counter()
+                op()
+                if cuda:
+                    torch.cuda.synchronize(device)
+                times.append(time.perf_counter() - t0)
+            times.sort()
+            return times[len(times) // 2] * 1e6
+        total = median_us(lambda: comm.all_reduce_sum_(buf))
+        launch = median_us(lambda: one.add_(1.0)) if cuda else 0.0
+        us = max(0.0, total - launch)
     return comm.all_reduce_max_scalar(us)
 
 
