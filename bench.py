@@ -484,6 +484,21 @@ def main() -> None:
                     extra["ant4096_fp32_transitions_per_sec"] = round(ups * 4096, 1)
                 except Exception as exc:
                     extra["ant4096_fp32_error"] = repr(exc)[:200]
+                # "episodes to reward target", the third stated metric, on the task that needs no data file: the built-in
+                # pendulum entirely on the GPU (8 device environments feed the HBM replay at 8 steps per update, the
+                # greedy TARGET policy is evaluated on 64 fresh episodes every 1000 updates; a random policy scores
+                # about -1200, -300 is a pendulum that swings up and stays up)
+                try:
+                    from d4pg_pytorch_amd.utils.learning import train_on_device
+                    r = train_on_device("d4pg", "fp32", updates=20_000, seed=103, eval_every=1000, device=device)
+                    hit = r["first_eval_step_above_-300"]
+                    extra["pendulum_target_return"] = -300.0
+                    extra["pendulum_updates_to_target"] = hit
+                    extra["pendulum_episodes_to_target"] = None if hit is None else int((2048 + 8 * hit) // 200)
+                    extra["pendulum_final_return"] = r["final_return"]
+                    extra["pendulum_learn_wall_s"] = r["wall_s"]
+                except Exception as exc:
+                    extra["pendulum_learn_error"] = repr(exc)[:200]
         elif args.dp_mode != "both":
             dp_mode = args.dp_mode
             core, dt = run_replicated() if dp_mode == "replicated" else run_grad_allreduce()
