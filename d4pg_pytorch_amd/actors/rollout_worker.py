@@ -17,6 +17,8 @@ it one insert launch per segment.
 """
 from __future__ import annotations
 
+import os
+import sys
 import time
 import traceback
 from typing import Dict
@@ -55,9 +57,7 @@ def run_rollout_worker(config: Dict, ctrl: ControlBlock, k: int, device_index: i
         raise ValueError(f"rollout_devices: no device-resident implementation of '{cfg['env']}'")
     rollout = DeviceRollout(cfg, env, _RowShape(cfg["state_dim"], cfg["action_dim"]), device, segment=segment, seed=seed)
 
-    import os
-    import sys
-    debug = bool(os.environ.get("D4PG_DEBUG_WORKER"))
+    debug = bool(os.environ.get("D4PG_DEBUG_WORKER"))      # a timeline of packs, segments and pushes on stderr
 
     def note(msg: str) -> None:
         if debug:
