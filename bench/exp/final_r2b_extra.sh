@@ -1,5 +1,5 @@
 #!/bin/bash
-# the rest of the round's evidence on the final kernels: GPU test log, per-layer stamps, whole topology (uniform / PER),
+# the remaining evidence on the final kernels: GPU test log, per-layer stamps, whole topology (uniform / PER),
 # device explorers (pendulum, lunar lander), rehearsal of the multi-rank paths
 O=gpurun_out/final_r2b_extra
 mkdir -p $O

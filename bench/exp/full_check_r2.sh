@@ -1,4 +1,4 @@
-# every headline / stress number of the round on ONE box, so that they are comparable with each other
+# every headline / stress number on ONE box, so that they are comparable with each other
 # (fp32 is the headline; every fp32 run on one GPU also times bf16 and reports it as bf16_value)
 set -e
 O=gpurun_out/${1:-final_r2}

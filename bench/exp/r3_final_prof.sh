@@ -1,5 +1,5 @@
 #!/bin/bash
-# End-of-round profile of the headline (fp32, batch 256) and of its prioritised-replay and exchange-mode variants: kernel
+# Profile of the headline (fp32, batch 256) and of its prioritised-replay and exchange-mode variants: kernel
 # times and one PMC pass, then the headline numbers of the other shapes on the same box.
 O=gpurun_out/r3_final
 mkdir -p $O

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 opening measurements on one box: the ant optimisation-level bisect, and PMC / kernel-time profiles of the
+# Opening measurements on one box: the ant optimisation-level bisect, and PMC / kernel-time profiles of the
 # fp32 pipeline at large batches (which of LDS reads, MFMA issue and L2 -> L1 weight traffic binds the 8 / 16-row tiles).
 O=gpurun_out/r3_first
 mkdir -p $O
