@@ -37,10 +37,22 @@ class _RowShape:
         raise RuntimeError("a rollout worker has no replay of its own")
 
 
+def worker_assignment(k: int, n_learners: int):
+    """(learner rank, index in that rank's mailbox) of rollout worker ``k``: workers are dealt to the learner ranks
+    round-robin, so that with data-parallel learners every rank's replay shard is fed."""
+    n = max(1, int(n_learners))
+    return k % n, k // n
+
+
+def workers_of_rank(n_workers: int, n_learners: int, rank: int) -> int:
+    return len([k for k in range(int(n_workers)) if worker_assignment(k, n_learners)[0] == rank])
+
+
 def run_rollout_worker(config: Dict, ctrl: ControlBlock, k: int, device_index: int, hb_slot: int,
                        max_segments: int = 0, stats: Dict = None) -> int:
     """Body of worker ``k``; returns the environment steps it delivered (``stats``, if given, receives the number of
-    policy refreshes and the last weight version packed)."""
+    policy refreshes and the last weight version packed).  The policy always comes from learner rank 0's weight slots
+    (all ranks hold the same parameters); the rows go to the mailbox of the rank the worker is dealt to."""
     import torch
     from ..envs.device_envs import make_device_env
     from ..parallel.hip_ipc import SharedDeviceBuffer, read_handle
@@ -71,10 +83,12 @@ def run_rollout_worker(config: Dict, ctrl: ControlBlock, k: int, device_index: i
         return ctrl.stop
 
     beat()
-    mailbox = RowMailbox.open(ctrl.name, device, should_stop=stopping)
+    n_learners = int(cfg.get("num_learners") or 1) if str(cfg.get("device", "cuda")).startswith("cuda") else 1
+    learner_rank, box = worker_assignment(k, n_learners)
+    mailbox = RowMailbox.open(ctrl.name, device, should_stop=stopping, learner_rank=learner_rank)
     if mailbox is None:
         return 0
-    if mailbox.rows_per_slot != n_envs * segment or k >= mailbox.n_workers:
+    if mailbox.rows_per_slot != n_envs * segment or box >= mailbox.n_workers:
         raise ValueError("rollout worker and learner disagree on the segment size or the number of workers")
     # the learner's weight slots: [online actor | target actor] x 2, written alternately (WeightPublisher)
     shared, n_actor, version = None, rollout.actor.layout.numel, 0
@@ -116,7 +130,7 @@ def run_rollout_worker(config: Dict, ctrl: ControlBlock, k: int, device_index: i
             note("segment done")
             rollout.drain(insert=False)
             with torch.cuda.stream(rollout.stream):
-                if not mailbox.push(k, rollout.rows, should_stop=stopping):
+                if not mailbox.push(box, rollout.rows, should_stop=stopping):
                     break
             note("pushed")
             n = n_envs * segment

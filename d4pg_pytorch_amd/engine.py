@@ -208,6 +208,10 @@ class Engine:
         if rollout_devices:
             import torch
             n_gpus = torch.cuda.device_count()          # (counting devices does not initialise the GPU in this process)
+            if world > 1 and n_explorers_per_rank == 0 and len(rollout_devices) < world:
+                raise ValueError(f"rollout_devices {rollout_devices}: {world} learner ranks are dealt the workers round-robin "
+                                 f"and there are no CPU explorers, so ranks {len(rollout_devices)}..{world - 1} would never "
+                                 f"see a transition: list at least {world} devices (an index may repeat)")
             missing = [d for d in rollout_devices if d >= n_gpus]
             if missing:
                 raise ValueError(f"rollout_devices {rollout_devices}: this machine has {n_gpus} GPU(s), no cuda:{missing[0]} "
@@ -284,9 +288,12 @@ class Engine:
             for r in rings:
                 r.close()
             slab.close()
-            for suffix in (".hipipc", ".rows.hipipc"):       # device weight handle, row staging ring of rollout workers
+            # device weight handle, row staging rings of the rollout workers (one per learner rank that is dealt workers)
+            from .parallel.row_mailbox import mailbox_path
+            for path in [os.path.join("/dev/shm", ctrl.name.strip("/") + ".hipipc")] + \
+                    [mailbox_path(ctrl.name, r) for r in range(world)]:
                 try:
-                    os.unlink(os.path.join("/dev/shm", ctrl.name.strip("/") + suffix))
+                    os.unlink(path)
                 except OSError:
                     pass
             ctrl.close()

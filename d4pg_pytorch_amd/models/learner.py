@@ -471,6 +471,7 @@ class Learner:
         ingest.close()
         if mailbox is not None:
             self.rows_from_workers = mailbox.rows_received
+            print(f"[learner {self.rank}] {mailbox.rows_received} rows from {mailbox.n_workers} rollout worker(s)", flush=True)
             mailbox.close()
         if dp is not None:
             drift = dp.check_consistency()
@@ -481,17 +482,21 @@ class Learner:
         self._finish()
 
     def _make_mailbox(self, replay):
-        """Staging ring in this GPU's memory for the rows of rollout workers on other GPUs (``rollout_devices``);
-        learner rank 0 only: every worker of the job delivers here."""
+        """Staging ring in this GPU's memory for the rows of the rollout workers dealt to this learner rank
+        (``rollout_devices``; round-robin over the ranks, ``actors/rollout_worker.py::worker_assignment``)."""
         cfg = self.config
         devs = cfg.get("rollout_devices") or []
-        if not devs or self.rank != 0 or self.device.type != "cuda":
+        if not devs or self.device.type != "cuda":
             return None
-        if self._shared is None:
+        from ..actors.rollout_worker import workers_of_rank
+        mine = workers_of_rank(len(devs), self.comm.world, self.rank)
+        if mine == 0:
+            return None
+        if self.rank == 0 and self._shared is None:
             raise RuntimeError("rollout_devices needs the learner's weights shared through HIP IPC (share_weights_ipc)")
         from ..parallel.row_mailbox import RowMailbox
         rows = int(cfg["gpu_rollout_envs"]) * int(cfg.get("gpu_rollout_segment", 32))
-        return RowMailbox.create(self.ctrl.name, len(devs), rows, replay.row_ld, self.device)
+        return RowMailbox.create(self.ctrl.name, mine, rows, replay.row_ld, self.device, learner_rank=self.rank)
 
     def _make_rollout(self, replay):
         """Explorers resident on this GPU (``gpu_rollout_envs`` > 0 and the environment exists as device

@@ -31,8 +31,11 @@ from .hip_ipc import SharedDeviceBuffer
 from .ipc import ControlBlock
 
 
-def mailbox_path(ctrl_name: str) -> str:
-    return os.path.join("/dev/shm", ctrl_name.strip("/") + ".rows.hipipc")
+def mailbox_path(ctrl_name: str, learner_rank: int = 0) -> str:
+    """Handle file of the mailbox of learner rank ``learner_rank`` (every learner rank that is dealt rollout workers
+    owns one, in its own GPU's memory)."""
+    suffix = ".rows.hipipc" if learner_rank == 0 else f".rows{int(learner_rank)}.hipipc"
+    return os.path.join("/dev/shm", ctrl_name.strip("/") + suffix)
 
 
 class RowMailbox:
@@ -50,14 +53,15 @@ class RowMailbox:
 
     # ------------------------------------------------------------------ learner side
     @staticmethod
-    def create(ctrl_name: str, n_workers: int, rows_per_slot: int, row_ld: int, device, slots: int = 3) -> "RowMailbox":
+    def create(ctrl_name: str, n_workers: int, rows_per_slot: int, row_ld: int, device, slots: int = 3,
+               learner_rank: int = 0) -> "RowMailbox":
         dev = torch.device(device)
         shared = SharedDeviceBuffer.create(n_workers * slots * rows_per_slot * row_ld, dev)
         counters = ControlBlock.create(n_workers=max(1, n_workers))
         meta = (shared.handle + int(shared.numel).to_bytes(8, "little") + int(dev.index or 0).to_bytes(4, "little")
                 + int(n_workers).to_bytes(4, "little") + int(slots).to_bytes(4, "little")
                 + int(rows_per_slot).to_bytes(4, "little") + int(row_ld).to_bytes(4, "little") + counters.name.encode())
-        path = mailbox_path(ctrl_name)
+        path = mailbox_path(ctrl_name, learner_rank)
         with open(path + ".tmp", "wb") as fh:
             fh.write(meta)
         os.replace(path + ".tmp", path)
@@ -94,9 +98,9 @@ class RowMailbox:
 
     # ------------------------------------------------------------------ worker side
     @staticmethod
-    def open(ctrl_name: str, device, timeout_s: float = 60.0, should_stop=None) -> Optional["RowMailbox"]:
-        """Map the learner's staging ring into this process (peer memory when ``device`` is another GPU)."""
-        path, deadline = mailbox_path(ctrl_name), time.time() + timeout_s
+    def open(ctrl_name: str, device, timeout_s: float = 60.0, should_stop=None, learner_rank: int = 0) -> Optional["RowMailbox"]:
+        """Map a learner rank's staging ring into this process (peer memory when ``device`` is another GPU)."""
+        path, deadline = mailbox_path(ctrl_name, learner_rank), time.time() + timeout_s
         while not os.path.exists(path):
             if time.time() > deadline or (should_stop is not None and should_stop()):
                 return None

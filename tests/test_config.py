@@ -130,3 +130,12 @@ def test_rollout_worker_config_loads_and_is_checked_against_the_machine():
     if torch.cuda.device_count() < 8:
         with pytest.raises(ValueError, match="rollout_devices"):
             load_engine(dict(cfg, num_steps_train=10, results_path="/tmp/d4pg_never_written")).train()
+
+
+def test_rollout_workers_are_dealt_to_the_learner_ranks_round_robin():
+    from d4pg_pytorch_amd.actors.rollout_worker import worker_assignment, workers_of_rank
+    from d4pg_pytorch_amd.parallel.row_mailbox import mailbox_path
+    assert [worker_assignment(k, 1) for k in range(3)] == [(0, 0), (0, 1), (0, 2)]
+    assert [worker_assignment(k, 2) for k in range(5)] == [(0, 0), (1, 0), (0, 1), (1, 1), (0, 2)]
+    assert [workers_of_rank(5, 2, r) for r in range(2)] == [3, 2] and workers_of_rank(1, 2, 1) == 0
+    assert mailbox_path("/x", 0).endswith("x.rows.hipipc") and mailbox_path("/x", 3).endswith("x.rows3.hipipc")

@@ -160,3 +160,27 @@ def test_killed_rollout_worker_is_replaced(tmp_path, monkeypatch):
     assert e.restarts == 1 and e.final_update_step == 400
     assert e.exit_codes["rollout-0"] == 0 and e.exit_codes["learner-0"] == 0
     assert e.final_env_steps >= 400 * 20
+
+
+def test_two_learner_ranks_are_each_fed_by_their_own_worker(tmp_path, monkeypatch, capfd):
+    """Data-parallel learners AND rollout workers: the workers are dealt to the learner ranks round-robin, every rank
+    owns a row mailbox in its GPU's memory, so every rank's replay shard is fed.  (Both ranks share the one GPU here,
+    so their collectives go through gloo: RCCL refuses two ranks on one device.)"""
+    import re
+    from d4pg_pytorch_amd.engine import load_engine
+    monkeypatch.setenv("D4PG_DIST_BACKEND", "gloo")
+    cfg = dict(env="Pendulum-v0", model="d4pg", num_agents=1, batch_size=128, num_steps_train=1500,
+               replay_mem_size=100_000, device="cuda", dense_size=128, v_min=-20, v_max=0, gpu_rollout_envs=64,
+               gpu_rollout_segment=16, num_learners=2, learner_devices=[0, 0], rollout_devices=[0, 0],
+               results_path=str(tmp_path / "results"))
+    e = load_engine(cfg)
+    e.train()
+    assert all(c == 0 for c in e.exit_codes.values()), e.exit_codes
+    assert set(e.exit_codes) == {"learner-0", "learner-1", "agent-0", "rollout-0", "rollout-1"}
+    assert e.final_update_step == 1500
+    out = capfd.readouterr().out
+    got = {int(m.group(1)): int(m.group(2)) for m in re.finditer(r"\[learner (\d)\] (\d+) rows from 1 rollout worker", out)}
+    assert set(got) == {0, 1} and min(got.values()) >= 64 * 16 * 4, (got, out[-2000:])
+    # a job whose ranks could not all be fed is refused before anything is spawned
+    with pytest.raises(ValueError, match="round-robin"):
+        load_engine(dict(cfg, rollout_devices=[0])).train()
