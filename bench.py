@@ -484,6 +484,29 @@ def main() -> None:
                     extra["ant4096_fp32_transitions_per_sec"] = round(ups * 4096, 1)
                 except Exception as exc:
                     extra["ant4096_fp32_error"] = repr(exc)[:200]
+                # "env steps/sec", the second stated metric, on one GPU: 4096 device-resident environments of this shape's
+                # task (policy with OU noise + dynamics + n-step rows, two launches per environment step, one captured
+                # graph per 32-step segment) feeding an HBM replay, nothing else on the GPU
+                try:
+                    from d4pg_pytorch_amd.actors.gpu_rollout import DeviceRollout
+                    from d4pg_pytorch_amd.envs.device_envs import make_device_env
+                    ecfg = default_config(**{**cfg, "env_backend": "native", "gpu_rollout_envs": 4096, "replay_mem_size": 1_000_000})
+                    ecore = build_core(ecfg, device)
+                    erp = HbmReplay(ecfg, device, ecore.dev_state)
+                    ero = DeviceRollout(ecfg, make_device_env(ecfg, 4096, device, 11), erp, device, segment=32, seed=12)
+                    ero.refresh_weights(ecore.online.flat.data_ptr(), ecore.layout.actor.base)
+                    for _ in range(3):
+                        ero.collect()
+                    torch.cuda.synchronize(device)
+                    t0 = time.perf_counter()
+                    n_env = sum(ero.collect() for _ in range(20))
+                    torch.cuda.synchronize(device)
+                    extra["env_steps_per_sec"] = round(n_env / (time.perf_counter() - t0), 1)
+                    extra["env_steps_config"] = "4096 device environments of %s (native simulator), 32-step segments" % env
+                    del ero, erp, ecore
+                    torch.cuda.empty_cache()
+                except Exception as exc:
+                    extra["env_steps_error"] = repr(exc)[:200]
                 # "episodes to reward target", the third stated metric, on the task that needs no data file: the built-in
                 # pendulum entirely on the GPU (8 device environments feed the HBM replay at 8 steps per update, the
                 # greedy TARGET policy is evaluated on 64 fresh episodes every 1000 updates; a random policy scores
