@@ -482,6 +482,9 @@ def main() -> None:
                                        "state_dim": 111, "action_dim": 8}, 320, 96)
                     extra["ant4096_fp32_ms_per_step"] = round(1000.0 / ups, 5)
                     extra["ant4096_fp32_transitions_per_sec"] = round(ups * 4096, 1)
+                    ups3 = quick_value({"env": "Ant-v2", "batch_size": 4096, "model": "d3pg", "state_dim": 111,
+                                        "action_dim": 8}, 320, 96)      # the scalar critic on the same shape
+                    extra["ant4096_d3pg_fp32_ms_per_step"] = round(1000.0 / ups3, 5)
                 except Exception as exc:
                     extra["ant4096_fp32_error"] = repr(exc)[:200]
                 # "env steps/sec", the second stated metric, on one GPU: 4096 device-resident environments of this shape's
