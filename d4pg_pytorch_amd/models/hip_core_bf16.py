@@ -1,19 +1,24 @@
-"""Fused row-local bf16 learner update (``compute_dtype: bf16``).
+"""Fused row-local bf16 learner update (``compute_dtype: bf16``), and the launch structure the fp32 twin
+(``models/hip_core_f32.py``) shares.
 
-Seven launches per update instead of 23 (see ``csrc/fused.hip``):
+Four launches per update instead of 23 (see ``csrc/fused.hip``), 32 updates per graph replay:
 
 ====  ===================================================================
- 1    replay_sample   (same kernel as the fp32 pipeline)
- 2    critic_phase    target actor -> target critic -> critic -> loss -> dX, per row tile
- 3    wgrad           dW/db of the three critic layers in one grouped launch
- 4    adam_polyak     critic Adam + Polyak + bf16 shadow refresh        [all-reduce before]
- 5    actor_phase     actor -> critic -> expected Q -> dX critic -> dX actor, per row tile
- 6    wgrad           dW/db of the three actor layers
- 7    adam_polyak     actor Adam + Polyak + shadow refresh, publishes the step   [all-reduce before]
+ 1    critic_phase    target actor -> target critic -> critic -> loss -> dX, per row tile
+                      (extra workgroups: the online actor's forward pass, L2 warmers)
+ 2    wgrad           dW/db of the three critic layers in one grouped launch; every tile applies Adam, Polyak and
+                      the refresh of the packed copies to the weights it has just reduced
+                      (extra workgroups: the priority write-back of prioritised replay)
+ 3    actor_phase     actor -> critic -> expected Q -> dX critic -> dX actor, per row tile
+                      (extra workgroups: the online critic's forward pass for the NEXT batch; with prioritised replay
+                      they draw that batch first)
+ 4    wgrad           the same for the three actor layers; publishes the step
 ====  ===================================================================
 
-Without data parallelism launches 4 and 7 disappear: each wgrad workgroup applies Adam,
-Polyak and the shadow refresh to the weight tile it has just reduced (5 launches per update).
+Batches are drawn ahead (uniform replay: a chunk of 32 per sampling launch, read in place), so no sampling launch
+belongs to an update.  With a gradient exchange (``grad_sync``) launches 2 and 4 only WRITE the gradients, the
+all-reduce follows (a node of the same graph with RCCL), and a second launch of the same kernel applies the summed
+gradients tile by tile (``apply_only``; ``dp_optimizer: flat`` selects the element-wise kernel of ``csrc/optim.hip``).
 
 Master weights, Adam state, gradients, logits and losses are fp32; only the MFMA
 operands (weights and activations) are rounded to bf16.  The public API, state

@@ -272,7 +272,7 @@ def resolve_dp_mode(mode: str, local_batch: int, world: int, compute_dtype: str 
     """``auto`` -> the cheaper of the two modes per update.  ``replicated`` pays the single-GPU update time of the
     GLOBAL batch; ``grad_allreduce`` that of the local batch, two all-reduces of a gradient bucket on the critical
     path (``allreduce_us`` each: measured on the live communicator by :func:`probe_allreduce_us` at attach time) and
-    the stand-alone optimiser kernels.  Without a measurement the static limits of ``REPLICATED_MAX_GLOBAL_BATCH``."""
+    the two launches that apply the summed gradients (``EXCHANGE_OVERHEAD_US``).  Without a measurement the static limits of ``REPLICATED_MAX_GLOBAL_BATCH``."""
     if mode != "auto":
         return mode
     if world <= 1:
