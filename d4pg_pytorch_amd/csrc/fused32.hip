@@ -5,8 +5,10 @@
 // and an update is four launches (critic phase, weight gradients + optimiser, actor phase, weight
 // gradients + optimiser) — but every product is an exact f32 multiply-add on the matrix cores:
 //
-//   phases : v_mfma_f32_4x4x1_16b_f32 on tiles of 4 * MT rows (csrc/mlp32_dev.h); weights streamed from
-//            fp32 copies packed in fragment order; activations, logits, losses, dX in fp32 in LDS
+//   phases : v_mfma_f32_4x4x1_16b_f32 on tiles of 4 * MT rows (csrc/mlp32_dev.h; one instance per hidden-width
+//            class, KSH > 0) or v_mfma_f32_16x16x4_f32 on tiles of 8 / 16 rows (csrc/mlp16_dev.h; widths at run
+//            time, KSH = 0); weights streamed from fp32 copies packed in the fragment order of the path;
+//            activations, logits, losses, dX in fp32 in LDS
 //   wgrad  : v_mfma_f32_32x32x2_f32 on fp32 stashes written by the phases in operand-fragment order,
 //            Adam + Polyak + refresh of the packed copies fused into the tile epilogue
 //

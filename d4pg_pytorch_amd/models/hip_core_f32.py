@@ -13,9 +13,12 @@ f32 multiply-add on the matrix cores — and the launch structure of :class:`Hip
  4    wgrad32         the same for the actor; publishes the step
 ====  ===================================================================
 
-``csrc/fused32.hip`` / ``csrc/mlp32_dev.h``: ``v_mfma_f32_4x4x1_16b_f32`` on 4-row tiles in the phases,
-``v_mfma_f32_32x32x2_f32`` in the weight gradients; weights are read from fp32 copies packed in
-fragment order (``Shadow32Layout``), which the optimiser inside ``wgrad32`` keeps current.
+``csrc/fused32.hip``: two sets of phase kernels.  ``csrc/mlp32_dev.h``: ``v_mfma_f32_4x4x1_16b_f32`` on tiles of
+4 / 8 / 16 rows, one compiled instance per hidden-width class of 32 (64, 100 / 128, 200, 256, 300, 400, 512) — the fast
+one while an update is a latency-bound chain.  ``csrc/mlp16_dev.h``: ``v_mfma_f32_16x16x4_f32`` on tiles of 8 / 16 rows,
+every width at run time — for batches that fill the chip (from 4096 rows) and for every other hidden width.
+``v_mfma_f32_32x32x2_f32`` in the weight gradients; weights are read from fp32 copies packed in the fragment order of
+the kernel set in use (``Shadow32Layout``), which the optimiser inside ``wgrad32`` keeps current.
 Everything else (drawn-ahead batches read in place, 32 updates per graph replay, critic forward made
 ahead, prioritised draw riding in the last launch, checkpoints, data-parallel wiring) is inherited.
 """
