@@ -245,7 +245,7 @@ def main() -> None:
         import torch.distributed as dist
         from d4pg_pytorch_amd.parallel.ipc import ControlBlock
         envs, seg = 4096, 32
-        DONE_SLOT = 10                          # a free fixed slot of the control block: workers that have finished
+        DONE_SLOT = ControlBlock.TOOL_SLOT0     # a free fixed slot of the control block: workers that have finished
         rcfg = default_config(**{**cfg, "gpu_rollout_envs": envs, "gpu_rollout_segment": seg, "env_backend": "native",
                                  "rollout_devices": list(range(1, world)), "replay_mem_size": 2_000_000,
                                  "num_steps_train": 10 ** 9})

@@ -281,6 +281,8 @@ class ControlBlock(_Shm):
     #: publications whose device-to-device copies have been ENQUEUED (>= completed).  Publication p (1-based) writes
     #: slot (p - 1) % 2, so a reader of publication v was overtaken iff this reads >= v + 2 when its pack has finished.
     GPU_WEIGHT_ISSUED = 8
+    #: slots 9 .. 15 are free for tools that share a control block (``bench.py`` counts finished rollout workers in 10)
+    TOOL_SLOT0 = 10
     N_FIXED = 16
 
     @classmethod
