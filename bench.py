@@ -97,6 +97,8 @@ def parse_args():
     ap.add_argument("--tile-rows", default="auto", choices=["auto", "4", "8", "16", "32"])
     ap.add_argument("--mfma", default="auto", choices=["auto", "4x4", "16x16"],
                     help="fp32 phase kernels: v_mfma_f32_4x4x1 (compiled hidden widths) or v_mfma_f32_16x16x4 (any width)")
+    ap.add_argument("--occupancy", default="auto", choices=["auto", "1", "2"],
+                    help="fp32 16x16x4 phase kernels: workgroups per CU (2: the lean build; auto: from 256 row tiles)")
     ap.add_argument("--hidden", type=int, default=400, help="dense_size (400: the reference's)")
     ap.add_argument("--dp-mode", default="both", choices=["both", "replicated", "grad_allreduce"],
                     help="data-parallel scheme for N > 1 (see the module docstring)")
@@ -166,7 +168,7 @@ def main() -> None:
                          dense_size=args.hidden, num_atoms=51, v_min=vrange[0], v_max=vrange[1],
                          device="cuda", replay_mem_size=args.replay_size,
                          replay_memory_prioritized=int(args.per), use_hip_graph=not args.no_graph,
-                         compute_dtype=args.dtype, phase_tile_rows=args.tile_rows, phase_mfma=args.mfma,
+                         compute_dtype=args.dtype, phase_tile_rows=args.tile_rows, phase_mfma=args.mfma, phase_occupancy=args.occupancy,
                          num_steps_train=max(1, args.steps * max(1, repeats) + args.warmup),
                          fused_learner="torch" if args.baseline else ("layers" if args.layers else "auto"), random_seed=2019)
     if args.chunk > 0:

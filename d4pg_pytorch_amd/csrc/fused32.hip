@@ -130,10 +130,19 @@ struct Chain32 {
 
 // KSH == 0: the 16x16x4 path of csrc/mlp16_dev.h (any widths, known at run time; tiles of 8 or 16 rows, MT = 2 / 4).
 // The same interface, so the roles below are written once.
+//
+// KSN selects one of two builds of that path.  0: four column tiles per wave and pass over K, ~170 registers, every
+// LDS tile in its own buffer: one workgroup per CU.  1 ("lean"): two column tiles per pass, at most 128 registers,
+// LDS tiles that are never live together share a buffer (lean_lds): TWO workgroups per CU, for grids of at least two
+// workgroups per CU.  A phase is a chain of layers; the 400 x 400 ones run at the fp32 matrix rate, everything between
+// them (row loads, narrow layers, K-slice reductions, the loss rows) leaves the matrix pipe idle, and only a second
+// workgroup on the same CU can use it meanwhile.
+constexpr bool lean_lds(int ksh, int ksn) { return ksh == 0 && ksn == 1; }
 template <int MT, int KSN>
 struct Chain32<MT, 0, KSN> {
     static_assert(MT == 2 || MT == 4, "the 16x16x4 path takes tiles of 8 or 16 rows");
-    Pre16 t0, t1;
+    static constexpr int TP = KSN == 1 ? TPW16_LEAN : TPW16;
+    Pre16<TP> t0, t1;
     float* red;
     int wave, lane;
     __device__ __forceinline__ Chain32(float* red_) : red(red_) {
@@ -142,31 +151,31 @@ struct Chain32<MT, 0, KSN> {
     }
     template <int SLOT>
     __device__ __forceinline__ void prefetch_h(const LayerW32& L) {
-        (SLOT == 0 ? t0 : t1) = fetch_pass16<NW32>(L, wave, lane, 0, true);
+        (SLOT == 0 ? t0 : t1) = fetch_pass16<NW32, TP>(L, wave, lane, 0, true);
     }
     template <int SLOT>
     __device__ __forceinline__ void prefetch_s(const LayerW32& L) {
-        (SLOT == 0 ? t0 : t1) = fetch_pass16<NW32>(L, wave, lane, 0, true);
+        (SLOT == 0 ? t0 : t1) = fetch_pass16<NW32, TP>(L, wave, lane, 0, true);
     }
     template <int SLOT>
     __device__ __forceinline__ void prefetch_n(const LayerW32& L) {
-        (SLOT == 0 ? t0 : t1) = fetch_pass16<NW32>(L, wave, lane, 0, true);
+        (SLOT == 0 ? t0 : t1) = fetch_pass16<NW32, TP>(L, wave, lane, 0, true);
     }
     template <int SLOT>
     __device__ __forceinline__ void prefetch_n_if(const LayerW32& L, bool run) {
-        (SLOT == 0 ? t0 : t1) = fetch_pass16<NW32>(L, wave, lane, 0, run);
+        (SLOT == 0 ? t0 : t1) = fetch_pass16<NW32, TP>(L, wave, lane, 0, run);
     }
     template <int SLOT, typename F, typename P>
     __device__ __forceinline__ void hidden(const float* A, int lda, const LayerW32& L, F&& epi, P&& pre, int = -1) {
-        layer16<NW32, 4 * MT>(SLOT == 0 ? t0 : t1, A, lda, L, red, epi, pre);
+        layer16<NW32, 4 * MT, TP>(SLOT == 0 ? t0 : t1, A, lda, L, red, epi, pre);
     }
     template <int SLOT, typename F, typename P>
     __device__ __forceinline__ void split(const float* A, int lda, const LayerW32& L, F&& epi, P&& pre) {
-        layer16<NW32, 4 * MT>(SLOT == 0 ? t0 : t1, A, lda, L, red, epi, pre);
+        layer16<NW32, 4 * MT, TP>(SLOT == 0 ? t0 : t1, A, lda, L, red, epi, pre);
     }
     template <int SLOT, typename F, typename P>
     __device__ __forceinline__ void narrow(const float* A, int lda, const LayerW32& L, F&& epi, P&& pre, int = -1) {
-        layer16<NW32, 4 * MT>(SLOT == 0 ? t0 : t1, A, lda, L, red, epi, pre);
+        layer16<NW32, 4 * MT, TP>(SLOT == 0 ? t0 : t1, A, lda, L, red, epi, pre);
     }
 };
 
@@ -243,7 +252,7 @@ __device__ __forceinline__ void warm_layer(const LayerW32& L, int slice, int nsl
 struct CriticAhead32 {
     int mode;        // 0: off; 1: only while the next batch is in the same chunk buffer; 2: always;
                      // 3: prioritised replay, the workgroups of the pass draw their rows of the next batch first
-    int pad_;
+    int role_map;    // how the two roles of a phase launch are dealt to its workgroups (role_of_block)
     float* h1;       // [B][ldh] relu(layer 1) row tiles (LDS images)
     float* h2;       // [B][ldh]
     float* lg;       // [B][nop] logits
@@ -305,6 +314,27 @@ struct ActorPhaseArgs32 {
 
 // (never on the 16x16x4 path: there a layer of any kind may be dealt out in K-slices)
 __host__ __device__ __forceinline__ bool critic_red_aliased(const PhaseDims& d, bool wide) { return !wide && (NW32 - 1) * 64 <= d.ldh; }
+// lean critic phase: the logits and their gradient go where the (s', a') tile was, when they fit there
+__host__ __device__ __forceinline__ bool lean_outputs_in_xin2(const PhaseDims& d) { return d.nop + d.ldd <= d.ldx; }
+
+// Which role and row tile a workgroup of a two-role phase launch takes.  role_map 0: the first n_tiles workgroups take
+// the long role, the next n_tiles the short one.  role_map 1 (n_tiles a multiple of 256): the roles alternate in runs of
+// 256 workgroups.  The dispatcher gives every CU one workgroup before it gives any a second one (measured: roles
+// alternating workgroup by workgroup inside an XCD put two long ones on one CU, 274 us instead of 219 for Ant at 4096
+// rows), so with two workgroups per CU a run of 256 long ones followed by 256 short ones pairs a long and a short one
+// on every CU; with more than 256 row tiles map 0 would start with two long ones everywhere.
+struct RoleTile {
+    int role;      // 0: long role, 1: short role, 2: beyond both
+    int tile;
+};
+__device__ __forceinline__ RoleTile role_of_block(int blk, int n_tiles, int role_map) {
+    if (blk >= 2 * n_tiles) return RoleTile{2, blk - 2 * n_tiles};
+    if (role_map == 1) {
+        const int g = blk >> 8;
+        return RoleTile{g & 1, ((g >> 1) << 8) | (blk & 255)};
+    }
+    return blk >= n_tiles ? RoleTile{1, blk - n_tiles} : RoleTile{0, blk};
+}
 
 // ---- loss rows: one wave per row ------------------------------------------------------------------
 struct CriticRowsOut {
@@ -464,17 +494,29 @@ __device__ __forceinline__ void critic_tail(const CriticPhaseArgs32& a, Chain32<
     STAMP(0, 12);
 }
 
+// (The lean build asks for four waves per SIMD, i.e. at most 128 registers; 2 is what a 512-thread workgroup implies.)
 template <int MT, int KSH, int KSN>
-__global__ __launch_bounds__(64 * NW32) void critic_phase32_kernel(const CriticPhaseArgs32) {
+__global__ __launch_bounds__(64 * NW32, lean_lds(KSH, KSN) ? 4 : 2) void critic_phase32_kernel(const CriticPhaseArgs32) {
     const CriticPhaseArgs32& a = kernel_args<CriticPhaseArgs32>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int M = 4 * MT;
     const PhaseDims& d = a.d;
-    const int row0 = blockIdx.x * M;
+    // Row tile and role of this workgroup.  (Only the lean build deals its roles in more than one way, and the code of
+    // the other builds is kept as it was: these kernels are sensitive to what the compiler makes of their first lines.)
+    int row0 = blockIdx.x * M;
+    bool warmer = row0 >= 2 * d.B, forward = row0 >= d.B;
+    unsigned warm_tile = blockIdx.x - 2 * (d.B / M);
+    if constexpr (lean_lds(KSH, KSN)) {
+        const RoleTile rt = role_of_block(blockIdx.x, d.B / M, a.ahead.role_map);
+        warmer = rt.role == 2;
+        forward = rt.role == 1;
+        warm_tile = rt.tile;
+        row0 = rt.tile * M + (forward ? d.B : 0);
+    }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (row0 >= 2 * d.B) {     // beyond both halves: L2 warmers
-        const int sl = (blockIdx.x - 2 * (d.B / M)) >> 3, nsl = (gridDim.x - 2 * (d.B / M) + 7) >> 3;
+    if (warmer) {              // beyond both halves: L2 warmers
+        const int sl = warm_tile >> 3, nsl = (gridDim.x - 2 * (d.B / M) + 7) >> 3;
         unsigned acc = 0;
         warm_layer(a.ta[0], sl, nsl, acc, KSH == 0);
         warm_layer(a.fwd.af[0], sl, nsl, acc, KSH == 0);
@@ -496,7 +538,7 @@ __global__ __launch_bounds__(64 * NW32) void critic_phase32_kernel(const CriticP
         STAMP_SPAN(0, 25, true);
         return;
     }
-    if (row0 >= d.B) {         // the second half of the grid: actor forward (+ the per-update tick)
+    if (forward) {             // the second half of the grid: actor forward (+ the per-update tick)
         STAMP_SPAN(0, 22, false);
         if (a.pk.do_tick && row0 == d.B && threadIdx.x == 0)
             devstate_tick(a.pk.st, a.pk.beta1, a.pk.beta2, a.pk.per_b0, a.pk.per_b1, a.pk.total_steps);
@@ -508,21 +550,33 @@ __global__ __launch_bounds__(64 * NW32) void critic_phase32_kernel(const CriticP
     STAMP(0, 31);
     int off = 0;
     auto carve = [&](int bytes) { char* p = smem + off; off += (bytes + 15) & ~15; return p; };
+    constexpr bool LEAN = lean_lds(KSH, KSN);
     float* xin = (float*)carve(M * d.ldx * 4);     // [s | a]
     float* xin2 = (float*)carve(M * d.ldx * 4);    // [s' | a']
     float* bufA = (float*)carve(M * d.ldh * 4);
     float* bufB = (float*)carve(M * d.ldh * 4);
-    float* bufC = (float*)carve(M * d.ldh * 4);    // h1 of the online critic (mask for the backward)
-    float* bufD = (float*)carve(M * d.ldh * 4);    // h2 of the online critic, then dh2 in place
-    float* dlg = (float*)carve(M * d.ldd * 4);
-    float* lg_t = (float*)carve(M * d.nop * 4);
-    float* lg_o = (float*)carve(M * d.nop * 4);
-    float* sp = (float*)carve(NW32 * ((d.NO + 63) & ~63) * 4);     // per-wave projection rows
+    // h1 / h2 of the online critic (masks for the backward; h2 becomes dh2 in place).  Lean: the target networks'
+    // tiles are dead once the target logits are out, the online critic's tiles take their place.
+    float* bufC = LEAN ? bufA : (float*)carve(M * d.ldh * 4);
+    float* bufD = LEAN ? bufB : (float*)carve(M * d.ldh * 4);
+    float *dlg, *lg_t, *lg_o;
+    if (LEAN && lean_outputs_in_xin2(d)) {         // (s', a') is dead once the target critic's first layer is through
+        lg_o = xin2;
+        dlg = xin2 + M * d.nop;
+        lg_t = (float*)carve(M * d.nop * 4);
+    } else {
+        dlg = (float*)carve(M * d.ldd * 4);
+        lg_t = (float*)carve(M * d.nop * 4);
+        lg_o = (float*)carve(M * d.nop * 4);
+    }
+    // per-wave projection rows of the loss (lean: where the partial sums are; no layer runs beside the loss rows)
+    float* sp = LEAN ? nullptr : (float*)carve(NW32 * ((d.NO + 63) & ~63) * 4);
     float* rs = (float*)carve(4 * M * 4);          // reward | 1 - done | gamma | weight / B
     // The K-slice partial sums of the three output layers (a', target logits, logits) go where bufA is:
     // its tile (an input of the hidden layer before) is dead whenever one of them runs.  Only when they
     // fit; a 16-row tile of a 400-wide network needs every byte of the LDS.
     float* red = critic_red_aliased(d, KSH == 0) ? bufA : (float*)carve(red_floats32(MT, KSH == 0) * 4);
+    if (LEAN) sp = red;
     Chain32<MT, KSH, KSN> ch(red);
     ch.template prefetch_n<0>(a.ta[0]);
     const int SA = d.S + d.A;
@@ -544,7 +598,7 @@ __global__ __launch_bounds__(64 * NW32) void critic_phase32_kernel(const CriticP
             rs_w = (a.weights ? a.weights[b] : 1.f) * d.inv_B;
         }
     }
-    zero_block(dlg, M * d.ldd * 4);
+    if (!LEAN) zero_block(dlg, M * d.ldd * 4);      // (lean: once its place is free, below)
     zero_tail(bufA, d.ldh, M, d.H);
     zero_tail(bufB, d.ldh, M, d.H);
     // Was the online critic's forward pass on exactly these rows made ahead, after the last change of
@@ -555,12 +609,16 @@ __global__ __launch_bounds__(64 * NW32) void critic_phase32_kernel(const CriticP
                    a.pk.st->pad_[AHEAD_ROWS] == (long long)(uintptr_t)src_sa.base;
     STAMP(0, 0);
     if (ahead_ok) {
-        copy16(bufC, a.ahead.h1 + (size_t)row0 * d.ldh, M * d.ldh * 4);
-        copy16(bufD, a.ahead.h2 + (size_t)row0 * d.ldh, M * d.ldh * 4);
-        copy16(lg_o, a.ahead.lg + (size_t)row0 * d.nop, M * d.nop * 4);
+        if (!LEAN) {      // (lean: their buffers hold the target networks' tiles until the target logits are out)
+            copy16(bufC, a.ahead.h1 + (size_t)row0 * d.ldh, M * d.ldh * 4);
+            copy16(bufD, a.ahead.h2 + (size_t)row0 * d.ldh, M * d.ldh * 4);
+            copy16(lg_o, a.ahead.lg + (size_t)row0 * d.nop, M * d.nop * 4);
+        }
     } else {
-        zero_tail(bufC, d.ldh, M, d.H);
-        zero_tail(bufD, d.ldh, M, d.H);
+        if (!LEAN) {
+            zero_tail(bufC, d.ldh, M, d.H);
+            zero_tail(bufD, d.ldh, M, d.H);
+        }
         load_input(src_sa, row0, M, SA, xin, d.ldx, a.saT, d.Bp);
     }
     load_input(src_s2, row0, M, d.S, xin2, d.ldx, nullptr, 0);
@@ -630,7 +688,13 @@ __global__ __launch_bounds__(64 * NW32) void critic_phase32_kernel(const CriticP
 #pragma unroll
             for (int r = 0; r < 4; ++r) lg_o[(r0 + r) * nop + col] = v[r];
         }, [] {});
+    } else if (LEAN) {
+        __syncthreads();      // the target critic's last layer has read bufB
+        copy16x4(bufC, a.ahead.h1 + (size_t)row0 * d.ldh, M * d.ldh * 4);
+        copy16x4(bufD, a.ahead.h2 + (size_t)row0 * d.ldh, M * d.ldh * 4);
+        copy16x4(lg_o, a.ahead.lg + (size_t)row0 * d.nop, M * d.nop * 4);
     }
+    if (LEAN) zero_block(dlg, M * d.ldd * 4);      // (the loss rows start behind a barrier)
     // No prefetched registers are live where the two paths join: the first backward layer is fetched
     // here and lands while the loss rows are computed.
     ch.template prefetch_n<1>(a.cb3);
@@ -713,16 +777,27 @@ __device__ __forceinline__ void critic_ahead_role(const ActorPhaseArgs32& a, int
 }
 
 template <int MT, int KSH, int KSN>
-__global__ __launch_bounds__(64 * NW32) void actor_phase32_kernel(const ActorPhaseArgs32) {
+__global__ __launch_bounds__(64 * NW32, lean_lds(KSH, KSN) ? 4 : 2) void actor_phase32_kernel(const ActorPhaseArgs32) {
     const ActorPhaseArgs32& a = kernel_args<ActorPhaseArgs32>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int M = 4 * MT;
     const PhaseDims& d = a.d;
-    const int row0 = blockIdx.x * M;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n_tree = a.tree.n > 0 ? (a.tree.parts > 1 ? a.tree.parts : 1) : 0;
     const int n_work = d.B / M + n_tree + (a.ahead.mode != 0 ? d.B / M : 0);
+    // the actor role and the critic's pass for the next update, dealt alternately (the host allows this without a tree role)
+    int row0 = blockIdx.x * M;
+    bool dealt = false;
+    if constexpr (lean_lds(KSH, KSN)) {      // (as in the critic phase: the other builds keep their code)
+        dealt = a.ahead.role_map == 1 && a.ahead.mode != 0 && (int)blockIdx.x < 2 * (d.B / M);
+        const RoleTile rt = role_of_block(blockIdx.x, d.B / M, dealt ? 1 : 0);
+        if (dealt && rt.role == 1) {
+            critic_ahead_role<MT, KSH, KSN>(a, rt.tile * M, smem);
+            return;
+        }
+        if (dealt) row0 = rt.tile * M;
+    }
     if ((int)blockIdx.x >= n_work) {                // L2 warmers
         const int sl = (blockIdx.x - n_work) >> 3, nsl = (gridDim.x - n_work + 7) >> 3;
         unsigned acc = 0;
@@ -737,22 +812,29 @@ __global__ __launch_bounds__(64 * NW32) void actor_phase32_kernel(const ActorPha
         asm volatile("" ::"v"(acc));
         return;
     }
-    if ((int)blockIdx.x >= d.B / M + n_tree) {      // the online critic's forward pass of the next update
+    if (!dealt && (int)blockIdx.x >= d.B / M + n_tree) {      // the online critic's forward pass of the next update
         critic_ahead_role<MT, KSH, KSN>(a, (blockIdx.x - (d.B / M + n_tree)) * M, smem);
         return;
     }
     if (row0 >= d.B) {         // the extra workgroups: priorities back into the tree
-        tree_update_body<NW32>(a.tree, (int)blockIdx.x - d.B / M, smem, 4 * M * d.ldh * 4);    // (the hidden tiles alone)
+        tree_update_body<NW32>(a.tree, (int)blockIdx.x - d.B / M, smem, (lean_lds(KSH, KSN) ? 2 : 4) * M * d.ldh * 4);    // (the hidden tiles alone)
         return;
     }
     STAMP(1, 31);
     int off = 0;
     auto carve = [&](int bytes) { char* p = smem + off; off += (bytes + 15) & ~15; return p; };
+    constexpr bool LEAN = lean_lds(KSH, KSN);
     float* xin = (float*)carve(M * d.ldx * 4);     // [s | pi(s)]
-    float* bufA = (float*)carve(M * d.ldh * 4);    // h1 actor
-    float* bufB = (float*)carve(M * d.ldh * 4);    // h2 actor, then dh2 actor in place
+    // h1 actor; h2 actor, then dh2 actor in place.  Lean: only needed as masks of the actor's backward layers, when
+    // the critic's tiles are dead: fetched into their buffers then.
+    float* bufA = LEAN ? nullptr : (float*)carve(M * d.ldh * 4);
+    float* bufB = LEAN ? nullptr : (float*)carve(M * d.ldh * 4);
     float* bufC = (float*)carve(M * d.ldh * 4);    // h1 critic, then dh1 critic in place
     float* bufD = (float*)carve(M * d.ldh * 4);    // h2 critic, then dh2 critic in place
+    if (LEAN) {
+        bufA = bufC;
+        bufB = bufD;
+    }
     float* dlg = (float*)carve(M * d.ldd * 4);
     float* dab = (float*)carve(M * d.lda_ * 4);
     float* lg_o = (float*)carve(M * d.nop * 4);
@@ -761,8 +843,10 @@ __global__ __launch_bounds__(64 * NW32) void actor_phase32_kernel(const ActorPha
     ch.template prefetch_n<0>(a.cf[0]);
     // ---- the actor forward pass of this tile was made alongside the critic phase ----
     copy16(xin, a.g_xin + (size_t)row0 * d.ldx, M * d.ldx * 4);
-    copy16(bufA, a.g_h1 + (size_t)row0 * d.ldh, M * d.ldh * 4);
-    copy16(bufB, a.g_h2 + (size_t)row0 * d.ldh, M * d.ldh * 4);
+    if (!LEAN) {
+        copy16(bufA, a.g_h1 + (size_t)row0 * d.ldh, M * d.ldh * 4);
+        copy16(bufB, a.g_h2 + (size_t)row0 * d.ldh, M * d.ldh * 4);
+    }
     zero_block(dlg, M * (d.ldd + d.lda_) * 4);      // dlg and dab are adjacent
     zero_tail(bufC, d.ldh, M, d.H);
     zero_tail(bufD, d.ldh, M, d.H);
@@ -811,6 +895,7 @@ __global__ __launch_bounds__(64 * NW32) void actor_phase32_kernel(const ActorPha
     }, [&] { ch.template prefetch_s<1>(a.cb1); });
     __syncthreads();
     STAMP(1, 6);
+    if (LEAN) copy16x4(bufB, a.g_h2 + (size_t)row0 * d.ldh, M * d.ldh * 4);      // dh2 critic is dead
     ch.template split<1>(bufC, ldh, a.cb1, [=](int r0, int col, f32x4 v) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -822,6 +907,7 @@ __global__ __launch_bounds__(64 * NW32) void actor_phase32_kernel(const ActorPha
     }, [&] { ch.template prefetch_n<0>(a.ab3); });
     __syncthreads();
     STAMP(1, 7);
+    if (LEAN) copy16x4(bufA, a.g_h1 + (size_t)row0 * d.ldh, M * d.ldh * 4);      // dh1 critic is dead
     // ---- actor backward ----
     ch.template narrow<0>(dab, lda_, a.ab3, [=](int r0, int col, f32x4 v) {
 #pragma unroll
@@ -926,14 +1012,17 @@ __global__ __launch_bounds__(64 * NW32) void actor_infer32_kernel(const ActorInf
 }
 
 // ---- host launchers -----------------------------------------------------------------------------
-static int lds_bytes_critic32(const PhaseDims& d, int M, int mt, bool wide = false) {
+static int lds_bytes_critic32(const PhaseDims& d, int M, int mt, bool wide = false, bool lean = false) {
     auto al = [](int b) { return (b + 15) & ~15; };
+    if (lean)      // (the carve-up of critic_phase32_kernel with lean_lds)
+        return 2 * al(M * d.ldx * 4) + 2 * al(M * d.ldh * 4) + (lean_outputs_in_xin2(d) ? 0 : al(M * d.ldd * 4) + al(M * d.nop * 4)) +
+               al(M * d.nop * 4) + al(4 * M * 4) + al(red_floats32(mt, true) * 4);
     return 2 * al(M * d.ldx * 4) + 4 * al(M * d.ldh * 4) + al(M * d.ldd * 4) + 2 * al(M * d.nop * 4) +
            al(NW32 * ((d.NO + 63) & ~63) * 4) + al(4 * M * 4) + (critic_red_aliased(d, wide) ? 0 : al(red_floats32(mt, wide) * 4));
 }
-static int lds_bytes_actor32(const PhaseDims& d, int M, int mt, bool wide = false) {
+static int lds_bytes_actor32(const PhaseDims& d, int M, int mt, bool wide = false, bool lean = false) {
     auto al = [](int b) { return (b + 15) & ~15; };
-    return al(M * d.ldx * 4) + 4 * al(M * d.ldh * 4) + al(M * d.ldd * 4) + al(M * d.lda_ * 4) + al(M * d.nop * 4) +
+    return al(M * d.ldx * 4) + (lean ? 2 : 4) * al(M * d.ldh * 4) + al(M * d.ldd * 4) + al(M * d.lda_ * 4) + al(M * d.nop * 4) +
            al(red_floats32(mt, wide) * 4);
 }
 
@@ -961,14 +1050,23 @@ D4PG_PHASE32_LAUNCHER(launch_actor32_ksh, actor_phase32_kernel, ActorPhaseArgs32
         if (mt == 2) return launch_phase(KERNEL<2, 0, 0>, *a, grid, NW32, lds, stream);                    \
         return launch_phase(KERNEL<4, 0, 0>, *a, grid, NW32, lds, stream);                                 \
     }
+// ... its lean build (two workgroups per CU; tiles of 16 rows)
+#define D4PG_PHASE32WL_LAUNCHER(NAME, KERNEL, ARGS)                                                       \
+    int NAME(const ARGS* a, int grid, int lds, hipStream_t stream) {                                       \
+        return launch_phase(KERNEL<4, 0, 1>, *a, grid, NW32, lds, stream);                                 \
+    }
 #if D4PG_KSH_PART == 0 || D4PG_KSH_PART == 99
 D4PG_PHASE32W_LAUNCHER(launch_critic32_wide, critic_phase32_kernel, CriticPhaseArgs32)
 D4PG_PHASE32W_LAUNCHER(launch_actor32_wide, actor_phase32_kernel, ActorPhaseArgs32)
 D4PG_PHASE32W_LAUNCHER(launch_infer32_wide, actor_infer32_kernel, ActorInferArgs32)
+D4PG_PHASE32WL_LAUNCHER(launch_critic32_lean, critic_phase32_kernel, CriticPhaseArgs32)
+D4PG_PHASE32WL_LAUNCHER(launch_actor32_lean, actor_phase32_kernel, ActorPhaseArgs32)
 #else
 int launch_critic32_wide(const CriticPhaseArgs32*, int, int, int, hipStream_t);
 int launch_actor32_wide(const ActorPhaseArgs32*, int, int, int, hipStream_t);
 int launch_infer32_wide(const ActorInferArgs32*, int, int, int, hipStream_t);
+int launch_critic32_lean(const CriticPhaseArgs32*, int, int, hipStream_t);
+int launch_actor32_lean(const ActorPhaseArgs32*, int, int, hipStream_t);
 #endif
 
 #define D4PG_PHASE32_INSTANCES(PREFIX, KSHV)                                                                   \
@@ -1068,6 +1166,7 @@ D4PG_API int d4pg_critic_phase32(const CriticPhaseArgs32* a, int mt, hipStream_t
         return -14;
     if (int prc = check_packed(a->pk, d)) return prc;
     if (a->ahead.mode != 0 && (a->ahead.h1 == nullptr || a->ahead.h2 == nullptr || a->ahead.lg == nullptr)) return -15;
+    if (a->ahead.role_map != 0) return -18;      // (the lean build only)
     const int extra_blocks = d.B / M + n_warmers32(d, M);      // the actor forward pass rides along, then the L2 warmers
     DISPATCH_PHASE32(launch_critic32_ksh, lds_bytes_critic32)
 }
@@ -1104,6 +1203,7 @@ D4PG_API int d4pg_actor_phase32(const ActorPhaseArgs32* a, int mt, hipStream_t s
             return prc;
         }
     }
+    if (a->ahead.role_map != 0) return -18;      // (the lean build only)
     const int n_ahead = a->ahead.mode != 0 ? d.B / M : 0;
     const int extra_blocks = (a->tree.n > 0 ? (a->tree.parts > 1 ? a->tree.parts : 1) : 0) + n_ahead + n_warmers32(d, M);
     DISPATCH_PHASE32(launch_actor32_ksh, lds_bytes_actor32)
@@ -1153,9 +1253,13 @@ static int check_dims16(const PhaseDims& d, int M) {
     return 0;
 }
 
-D4PG_API int d4pg_critic_phase32w(const CriticPhaseArgs32* a, int mt, hipStream_t stream) {
+// LDS a workgroup may ask for while two of them still fit a CU (160 KB, allocated in units of 1280 bytes)
+constexpr int LEAN_LDS_LIMIT = 81920;
+
+static int critic_phase32w(const CriticPhaseArgs32* a, int mt, bool lean, hipStream_t stream) {
     const PhaseDims& d = a->d;
     if (mt != 2 && mt != 4) return -9;
+    if (lean && (mt != 4 || lds_bytes_critic32(d, 16, 4, true, true) > LEAN_LDS_LIMIT)) return -17;
     const int M = 4 * mt;
     if (int rc = check_dims16(d, M)) return rc;
     const LayerW32* nets[4] = {a->ta, a->tc, a->cf, a->fwd.af};
@@ -1171,13 +1275,18 @@ D4PG_API int d4pg_critic_phase32w(const CriticPhaseArgs32* a, int mt, hipStream_
         return -14;
     if (int prc = check_packed(a->pk, d)) return prc;
     if (a->ahead.mode != 0 && (a->ahead.h1 == nullptr || a->ahead.h2 == nullptr || a->ahead.lg == nullptr)) return -15;
+    if (a->ahead.role_map != 0 && (!lean || a->ahead.role_map != 1 || (d.B / M) % 256)) return -18;
     const int grid = 2 * (d.B / M) + n_warmers32(d, M);
+    if (lean) return launch_critic32_lean(a, grid, lds_bytes_critic32(d, M, mt, true, true), stream);
     return launch_critic32_wide(a, mt, grid, lds_bytes_critic32(d, M, mt, true), stream);
 }
+D4PG_API int d4pg_critic_phase32w(const CriticPhaseArgs32* a, int mt, hipStream_t stream) { return critic_phase32w(a, mt, false, stream); }
+D4PG_API int d4pg_critic_phase32wl(const CriticPhaseArgs32* a, int mt, hipStream_t stream) { return critic_phase32w(a, mt, true, stream); }
 
-D4PG_API int d4pg_actor_phase32w(const ActorPhaseArgs32* a, int mt, hipStream_t stream) {
+static int actor_phase32w(const ActorPhaseArgs32* a, int mt, bool lean, hipStream_t stream) {
     const PhaseDims& d = a->d;
     if (mt != 2 && mt != 4) return -9;
+    if (lean && (mt != 4 || lds_bytes_actor32(d, 16, 4, true, true) > LEAN_LDS_LIMIT)) return -17;
     const int M = 4 * mt;
     if (int rc = check_dims16(d, M)) return rc;
     if (int rc = check_layer16(a->cf[0], d.ldx)) return rc;
@@ -1204,10 +1313,14 @@ D4PG_API int d4pg_actor_phase32w(const ActorPhaseArgs32* a, int mt, hipStream_t 
             return prc;
         }
     }
+    if (a->ahead.role_map != 0 && (!lean || a->ahead.role_map != 1 || (d.B / M) % 256 || a->tree.n > 0)) return -18;
     const int n_ahead = a->ahead.mode != 0 ? d.B / M : 0;
     const int grid = d.B / M + (a->tree.n > 0 ? (a->tree.parts > 1 ? a->tree.parts : 1) : 0) + n_ahead + n_warmers32(d, M);
+    if (lean) return launch_actor32_lean(a, grid, lds_bytes_actor32(d, M, mt, true, true), stream);
     return launch_actor32_wide(a, mt, grid, lds_bytes_actor32(d, M, mt, true), stream);
 }
+D4PG_API int d4pg_actor_phase32w(const ActorPhaseArgs32* a, int mt, hipStream_t stream) { return actor_phase32w(a, mt, false, stream); }
+D4PG_API int d4pg_actor_phase32wl(const ActorPhaseArgs32* a, int mt, hipStream_t stream) { return actor_phase32w(a, mt, true, stream); }
 
 D4PG_API int d4pg_actor_infer32w(const ActorInferArgs32* a, int mt, hipStream_t stream) {
     if (mt != 2 && mt != 4) return -9;
@@ -1226,6 +1339,11 @@ D4PG_API int d4pg_actor_infer32w(const ActorInferArgs32* a, int mt, hipStream_t 
 D4PG_API int d4pg_phase32w_lds_bytes(const PhaseDims* d, int mt, int actor) {
     return actor ? lds_bytes_actor32(*d, 4 * mt, mt, true) : lds_bytes_critic32(*d, 4 * mt, mt, true);
 }
+// the lean build (16-row tiles); d4pg_phase32wl_lds_limit: what two workgroups per CU allow
+D4PG_API int d4pg_phase32wl_lds_bytes(const PhaseDims* d, int actor) {
+    return actor ? lds_bytes_actor32(*d, 16, 4, true, true) : lds_bytes_critic32(*d, 16, 4, true, true);
+}
+D4PG_API int d4pg_phase32wl_lds_limit() { return LEAN_LDS_LIMIT; }
 
 D4PG_API int d4pg_phase32_lds_bytes(const PhaseDims* d, int mt, int actor) {
     return actor ? lds_bytes_actor32(*d, 4 * mt, mt) : lds_bytes_critic32(*d, 4 * mt, mt);

@@ -23,6 +23,8 @@
 constexpr int GROUP16_FLOATS = 256;        // one (16-column tile, 16-k group) block
 constexpr int GROUP16_BYTES = 1024;
 constexpr int TPW16 = 4;                   // column tiles a wave multiplies in one pass over K
+constexpr int TPW16_LEAN = 2;              // ... in the kernels built for two workgroups per CU (half the registers per wave:
+                                           // accumulators, weight ring and prefetch slots all scale with this number)
 
 __host__ __device__ __forceinline__ long long packed16_off(int n, int k, int kgs) {
     return (((long long)(n >> 4) * kgs + (k >> 4)) << 8) + ((((k >> 2) & 3) << 4) + (n & 15)) * 4 + (k & 3);
@@ -32,27 +34,30 @@ __host__ __device__ __forceinline__ long long packed16_off(int n, int k, int kgs
 // tiles of 16, N = outputs, ksplit = K-slices (> 1 only when ntiles * ksplit <= waves), nch = k-groups
 // per slice; kg is not used.
 //
-// Work of wave w of NW:  ksplit == 1: column tiles w, w + NW, w + 2 NW, ... (TPW16 of them per pass over K);
+// Work of wave w of NW:  ksplit == 1: column tiles w, w + NW, w + 2 NW, ... (TP of them per pass over K);
 // ksplit > 1: tile w % ntiles, K-slice w / ntiles, the slices of a tile meeting through `red`.
+template <int TP>
 struct Grp16 {
-    f32x4 b[TPW16];      // B fragments of one k-group for up to TPW16 column tiles
+    f32x4 b[TP];         // B fragments of one k-group for up to TP column tiles
 };
+template <int TP>
 struct Pre16 {
-    Grp16 g[2];          // the first two k-groups of the wave's first pass
+    Grp16<TP> g[2];      // the first two k-groups of the wave's first pass
 };
+template <int TP>
 struct Unit16 {
     __amdgpu_buffer_rsrc_t rsrc;
-    int voff[TPW16];     // this lane's byte offset inside a group, out of range for tiles the wave does not own
-    int soff[TPW16];     // scalar byte offset of the tile's first k-group
+    int voff[TP];        // this lane's byte offset inside a group, out of range for tiles the wave does not own
+    int soff[TP];        // scalar byte offset of the tile's first k-group
     int g0, g1;          // k-groups [g0, g1) of the wave's slice
     int tiles;           // column tiles of this pass (0: the wave idles)
     int tile0;           // the first of them; the others follow at a stride of NW (ksplit == 1)
     int oob;
 };
 
-template <int NW>
-__device__ __forceinline__ Unit16 unit16_of(const LayerW32& L, int wave, int lane, int pass) {
-    Unit16 u;
+template <int NW, int TP>
+__device__ __forceinline__ Unit16<TP> unit16_of(const LayerW32& L, int wave, int lane, int pass) {
+    Unit16<TP> u;
     const int bytes = L.ntiles * L.ks * GROUP16_BYTES;
     u.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)L.W, 0, bytes, 0x00020000);
     u.oob = bytes;
@@ -64,14 +69,14 @@ __device__ __forceinline__ Unit16 unit16_of(const LayerW32& L, int wave, int lan
         u.tile0 = wave - slice * L.ntiles;
         u.tiles = has ? 1 : 0;
     } else {
-        u.tile0 = wave + pass * TPW16 * NW;
+        u.tile0 = wave + pass * TP * NW;
         const int left = L.ntiles - u.tile0;
-        u.tiles = left <= 0 ? 0 : min(TPW16, (left + NW - 1) / NW);
+        u.tiles = left <= 0 ? 0 : min(TP, (left + NW - 1) / NW);
     }
     u.g0 = slice * L.nch;
     u.g1 = min(L.ks, u.g0 + L.nch);      // (never empty: the host checks (ksplit - 1) * nch < ks)
 #pragma unroll
-    for (int j = 0; j < TPW16; ++j) {
+    for (int j = 0; j < TP; ++j) {
         const int tile = u.tile0 + j * NW;
         u.voff[j] = j < u.tiles ? lane * 16 : bytes;
         u.soff[j] = j < u.tiles ? tile * L.ks * GROUP16_BYTES : 0;
@@ -81,8 +86,8 @@ __device__ __forceinline__ Unit16 unit16_of(const LayerW32& L, int wave, int lan
 
 // k-group g of the wave's tiles; a group beyond the slice reads nothing (offsets out of range return zeros
 // without a fetch), so every load is unconditional and the compiler's count of loads in flight stays exact
-template <int T>
-__device__ __forceinline__ void load_grp16(Grp16& r, const Unit16& u, int g) {
+template <int T, int TP>
+__device__ __forceinline__ void load_grp16(Grp16<TP>& r, const Unit16<TP>& u, int g) {
     const bool in = g < u.g1;
 #pragma unroll
     for (int j = 0; j < T; ++j)
@@ -93,8 +98,8 @@ __device__ __forceinline__ void load_grp16(Grp16& r, const Unit16& u, int g) {
 
 // acc[t][.] += x[16 rows][16 k of the group] * W[tile t][the same k]; the two accumulators of a tile alternate,
 // so consecutive MFMAs of a wave with one tile do not wait for each other (40-cycle result latency, 32-cycle issue)
-template <int T>
-__device__ __forceinline__ void mma_grp16(const f32x4& a, const Grp16& r, f32x4 (&acc)[TPW16][2]) {
+template <int T, int TP>
+__device__ __forceinline__ void mma_grp16(const f32x4& a, const Grp16<TP>& r, f32x4 (&acc)[TP][2]) {
 #pragma unroll
     for (int j4 = 0; j4 < 4; ++j4)
 #pragma unroll
@@ -128,9 +133,9 @@ __device__ __forceinline__ f32x4 lds_frag16(const float* p) { return *reinterpre
 __device__ __forceinline__ void lds_frag16_wait() {}
 #endif
 
-template <int T>
-__device__ __forceinline__ void pass16(const Unit16& u, const Pre16& t, const float* Al, f32x4 (&acc)[TPW16][2]) {
-    Grp16 r[RING16];
+template <int T, int TP>
+__device__ __forceinline__ void pass16(const Unit16<TP>& u, const Pre16<TP>& t, const float* Al, f32x4 (&acc)[TP][2]) {
+    Grp16<TP> r[RING16];
     r[0] = t.g[0];
     r[1] = t.g[1];
 #pragma unroll
@@ -165,16 +170,16 @@ __device__ __forceinline__ void pass16(const Unit16& u, const Pre16& t, const fl
 // reads zeros from out-of-range offsets).  Pass 0 is issued by the layer BEFORE, so the stream of weight
 // loads of a workgroup does not stop at a layer boundary.
 // (`run` false, wave-uniform: a layer that is going to be skipped; nothing is fetched)
-template <int NW>
-__device__ __forceinline__ Pre16 fetch_pass16(const LayerW32& L, int wave, int lane, int pass, bool run) {
-    Unit16 u = unit16_of<NW>(L, wave, lane, pass);
+template <int NW, int TP>
+__device__ __forceinline__ Pre16<TP> fetch_pass16(const LayerW32& L, int wave, int lane, int pass, bool run) {
+    Unit16<TP> u = unit16_of<NW, TP>(L, wave, lane, pass);
     if (!run) {
 #pragma unroll
-        for (int j = 0; j < TPW16; ++j) u.voff[j] = u.oob;
+        for (int j = 0; j < TP; ++j) u.voff[j] = u.oob;
     }
-    Pre16 t;
-    load_grp16<TPW16>(t.g[0], u, u.g0);
-    load_grp16<TPW16>(t.g[1], u, u.g0 + 1);
+    Pre16<TP> t;
+    load_grp16<TP>(t.g[0], u, u.g0);
+    load_grp16<TP>(t.g[1], u, u.g0 + 1);
     return t;
 }
 
@@ -184,20 +189,20 @@ __device__ __forceinline__ Pre16 fetch_pass16(const LayerW32& L, int wave, int l
 // t   : the first two k-groups of this wave's first pass (fetch_pass16, issued by the layer before)
 // red : LDS scratch for K-slice partial sums, (NW - 1) * 256 floats
 // pre : issues the loads of the NEXT layer's first groups; ONE call site, behind this layer's last own load
-template <int NW, int M, typename F, typename P>
-__device__ __forceinline__ void layer16(Pre16& t, const float* A, int lda, const LayerW32& L, float* red, F&& epi, P&& pre) {
+template <int NW, int M, int TP, typename F, typename P>
+__device__ __forceinline__ void layer16(Pre16<TP>& t, const float* A, int lda, const LayerW32& L, float* red, F&& epi, P&& pre) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 15, q = lane >> 4;
     const float* Al = A + (c & (M - 1)) * lda + 4 * q;
     const bool split = L.ksplit > 1;
-    const int passes = split ? 1 : (L.ntiles + TPW16 * NW - 1) / (TPW16 * NW);
-    for (int pass = 0; pass < passes; ++pass) {      // (more than one: layers wider than 16 * TPW16 * NW = 512)
-        const Unit16 u = unit16_of<NW>(L, wave, lane, pass);
-        f32x4 acc[TPW16][2];
-        float bias[TPW16];
+    const int passes = split ? 1 : (L.ntiles + TP * NW - 1) / (TP * NW);
+    for (int pass = 0; pass < passes; ++pass) {      // (more than one: layers wider than 16 * TP * NW = 512 / 256)
+        const Unit16<TP> u = unit16_of<NW, TP>(L, wave, lane, pass);
+        f32x4 acc[TP][2];
+        float bias[TP];
 #pragma unroll
-        for (int j = 0; j < TPW16; ++j) {
+        for (int j = 0; j < TP; ++j) {
             acc[j][0] = acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
             const int col = (u.tile0 + j * NW) * 16 + c;
             bias[j] = L.bias[(j < u.tiles && col < L.N) ? col : 0];
@@ -205,11 +210,11 @@ __device__ __forceinline__ void layer16(Pre16& t, const float* A, int lda, const
         switch (u.tiles) {      // wave-uniform
             case 1: pass16<1>(u, t, Al, acc); break;
             case 2: pass16<2>(u, t, Al, acc); break;
-            case 3: pass16<3>(u, t, Al, acc); break;
-            case 4: pass16<4>(u, t, Al, acc); break;
+            case 3: if constexpr (TP >= 3) pass16<3>(u, t, Al, acc); break;
+            case 4: if constexpr (TP >= 4) pass16<4>(u, t, Al, acc); break;
             default: break;
         }
-        if (pass + 1 < passes) t = fetch_pass16<NW>(L, wave, lane, pass + 1, true);
+        if (pass + 1 < passes) t = fetch_pass16<NW, TP>(L, wave, lane, pass + 1, true);
         else pre();
         bool write = u.tiles > 0 && 4 * q < M;
         if (split) {      // workgroup-uniform; the slices of a tile meet through `red`, slice 0 finishes the tile
@@ -224,7 +229,7 @@ __device__ __forceinline__ void layer16(Pre16& t, const float* A, int lda, const
         }
         if (write) {
 #pragma unroll
-            for (int j = 0; j < TPW16; ++j) {
+            for (int j = 0; j < TP; ++j) {
                 const int col = (u.tile0 + j * NW) * 16 + c;
                 if (j < u.tiles && col < L.N) {
                     f32x4 v = acc[j][0] + acc[j][1];

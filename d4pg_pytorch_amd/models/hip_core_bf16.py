@@ -53,6 +53,8 @@ class HipCoreBf16(HipCore):
     #: prioritised replay: the actor-phase launch can also draw the next batch (behind its own tree update) and
     #: make the online critic's forward pass on it (``CriticAhead`` mode 3, csrc/fused32.hip)
     supports_per_ahead = False
+    ahead_tiles = 128        # row tiles up to which an actor-phase launch leaves room for the critic's forward pass
+    role_map = 0             # how the two roles of a phase launch are dealt to its workgroups (csrc/fused32.hip, role_of_block)
     #: gradient-exchange mode: apply the summed gradients with a tile-shaped launch of the weight-gradient kernel
     #: (``apply_only``) instead of the flat element-wise optimiser kernel
     supports_apply_only = True
@@ -126,7 +128,7 @@ class HipCoreBf16(HipCore):
         self.packed_direct[name] = pk
         # moving the pass to the other launch only pays while that launch leaves compute units idle
         # (batch 4096: 93.9 us per update without, 98.6 us with)
-        fits = self.B // (self.rows_per_tile_unit * self.mt) <= 128
+        fits = self.B // (self.rows_per_tile_unit * self.mt) <= self.ahead_tiles
         self.direct_ahead[name] = int(critic_ahead) if fits and int(os.environ.get("D4PG_CRITIC_AHEAD", "1")) else 0
         self.packed_unpack.pop(name, None)
         self._graphs = {k: v for k, v in self._graphs.items() if not k.startswith(name)}
@@ -417,6 +419,7 @@ class HipCoreBf16(HipCore):
                 f.g_pi = self.g_pi.data_ptr()
             ah = a.ahead
             ah.mode = 3 if per_ahead else self.direct_ahead.get(source, 0)
+            ah.role_map = self.role_map
             ah.h1, ah.h2, ah.lg = self.gc_h1.data_ptr(), self.gc_h2.data_ptr(), self.gc_lg.data_ptr()
             H._check(getattr(H.lib(), self._fn_critic)(a, self.mt, H.stream_ptr()), self._fn_critic)
             # the priority write-back rides along with the actor phase (seg_actor)
@@ -465,6 +468,7 @@ class HipCoreBf16(HipCore):
                 ah = a.ahead
                 ah.mode = 3
                 ah.h1, ah.h2, ah.lg = self.gc_h1.data_ptr(), self.gc_h2.data_ptr(), self.gc_lg.data_ptr()
+            a.ahead.role_map = self.role_map if (a.ahead.mode != 0 and a.tree.n == 0) else 0
             H._check(getattr(H.lib(), self._fn_actor)(a, self.mt, H.stream_ptr()), self._fn_actor)
             self._wgrad(actor_triples,
                         opt=(self.lr_actor, True) if fuse_opt else None, sample_next=per_role and not per_ahead)

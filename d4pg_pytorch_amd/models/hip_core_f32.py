@@ -39,6 +39,11 @@ LDS_PAD32 = 4
 #: 107 / 144, 2048 145 / 158 (128 tiles of 16 rows leave half the chip to the short roles of each launch), 4096
 #: 253 / 221; Ant shape batch 4096 301 / 238.
 WIDE_FROM_BATCH = 4096
+#: row tiles from which the lean build of the 16x16x4 kernels runs (two workgroups per CU: at most 128 registers per
+#: lane and 80 KB of LDS per workgroup, tiles that are never live together sharing a buffer).  From here every phase
+#: launch holds at least two workgroups for each of the 256 CUs, and the second one multiplies while the first loads
+#: rows, reduces K-slices or computes loss rows.
+LEAN_FROM_TILES = 256
 
 
 class HipCoreF32(HipCoreBf16):
@@ -48,6 +53,7 @@ class HipCoreF32(HipCoreBf16):
     rows_per_tile_unit = 4
     supports_per_ahead = True
     wide = False
+    lean = False
 
     def __init__(self, cfg: Dict, device="cuda", seed: Optional[int] = None):
         HipCore.__init__(self, cfg, device, seed)
@@ -121,6 +127,18 @@ class HipCoreF32(HipCoreBf16):
         need = lds_need(self.mt)
         if need > LDS_LIMIT:
             raise ShapeLimit(f"dense_size={Hd} needs {need} bytes of LDS per workgroup (> {LDS_LIMIT})")
+        # the lean build: phase_occupancy: auto | 1 | 2 (workgroups per CU)
+        occ = str(cfg.get("phase_occupancy", "auto"))
+        lean_fits = self.wide and self.mt == 4 and max(H.lib().d4pg_phase32wl_lds_bytes(self.dims, 0),
+                                                       H.lib().d4pg_phase32wl_lds_bytes(self.dims, 1)) <= H.lib().d4pg_phase32wl_lds_limit()
+        if occ == "2" and not lean_fits:
+            raise ShapeLimit("phase_occupancy: 2 needs the 16x16x4 kernels on 16-row tiles and <= 80 KB of LDS per workgroup")
+        self.lean = lean_fits and (occ == "2" or (occ == "auto" and B // 16 >= LEAN_FROM_TILES))
+        if self.lean:
+            self._fn_critic, self._fn_actor = "d4pg_critic_phase32wl", "d4pg_actor_phase32wl"
+            self.ahead_tiles = 256        # the critic's forward pass rides in the actor launch while both fit the chip twice
+            import os
+            self.role_map = int(os.environ.get("D4PG_ROLE_MAP", "1")) if (B // 16) % 256 == 0 else 0
         self.refresh_shadows()
 
     # ------------------------------------------------------------------ shadows

@@ -179,7 +179,7 @@ class ActorFwd(C.Structure):
 
 
 class CriticAhead(C.Structure):
-    _fields_ = [("mode", C.c_int), ("pad_", C.c_int), ("h1", vp), ("h2", vp), ("lg", vp)]
+    _fields_ = [("mode", C.c_int), ("role_map", C.c_int), ("h1", vp), ("h2", vp), ("lg", vp)]
 
 
 class CriticPhaseArgs(C.Structure):
@@ -454,6 +454,10 @@ def lib() -> C.CDLL:
             ("d4pg_actor_phase32w", [C.POINTER(ActorPhaseArgs32), C.c_int, vp]),
             ("d4pg_actor_infer32w", [C.POINTER(ActorInferArgs32), C.c_int, vp]),
             ("d4pg_phase32w_lds_bytes", [C.POINTER(PhaseDims), C.c_int, C.c_int]),
+            ("d4pg_critic_phase32wl", [C.POINTER(CriticPhaseArgs32), C.c_int, vp]),
+            ("d4pg_actor_phase32wl", [C.POINTER(ActorPhaseArgs32), C.c_int, vp]),
+            ("d4pg_phase32wl_lds_bytes", [C.POINTER(PhaseDims), C.c_int]),
+            ("d4pg_phase32wl_lds_limit", []),
             ("d4pg_wgrad32", [C.POINTER(WgradGroup32), vp]),
             ("d4pg_actor_infer32", [C.POINTER(ActorInferArgs32), C.c_int, vp]),
             ("d4pg_pack_actor32", [C.POINTER(PackActorArgs32), vp]),

@@ -46,7 +46,12 @@ CASES = [("d4pg", {}), ("d4pg", {"critic_loss": "ce", "dense_size": 128}), ("d3p
          ("d4pg", {"dense_size": 180, "batch_size": 136}),                                    # 8-row tiles (136 = 8 * 17)
          # the widths of D4PG_KSH_LIST (csrc/fused32.hip) on their compile-time 4x4x1 kernels
          ("d4pg", {"dense_size": 64}), ("d4pg", {"dense_size": 200}), ("d3pg", {"dense_size": 300, "env": "Walker2d-v2"}),
-         ("d4pg", {"dense_size": 300}), ("d4pg", {"dense_size": 512}), ("d4pg", {"dense_size": 500, "batch_size": 1024})]
+         ("d4pg", {"dense_size": 300}), ("d4pg", {"dense_size": 512}), ("d4pg", {"dense_size": 500, "batch_size": 1024}),
+         # the lean build of the 16x16x4 kernels (two workgroups per CU; LDS tiles sharing buffers)
+         ("d4pg", {"env": "BipedalWalker-v2", "phase_mfma": "16x16", "phase_occupancy": "2"}),
+         ("d4pg", {"env": "Ant-v2", "phase_mfma": "16x16", "phase_occupancy": "2"}),          # logits where (s', a') was
+         ("d3pg", {"env": "Walker2d-v2", "dense_size": 300, "batch_size": 512, "phase_mfma": "16x16", "phase_occupancy": "2"}),
+         ("d4pg", {"env": "Ant-v2", "batch_size": 4096})]                                     # what `auto` runs from 256 row tiles
 
 def test_default_dtype_is_the_fused_fp32_pipeline():
     """``compute_dtype: auto`` is reference precision; shapes outside the fused kernels fall back to the
@@ -167,15 +172,18 @@ def test_f32_update_from_replay_and_resume(per, tmp_path):
     torch.testing.assert_close(other.online.flat, core.online.flat, rtol=0, atol=0)
 
 
-def test_f32_drawn_ahead_chunks_equal_one_update_at_a_time():
+@pytest.mark.parametrize("kw", [{}, {"phase_mfma": "16x16"}, {"phase_mfma": "16x16", "phase_occupancy": "2"},
+                                {"env": "Ant-v2", "phase_mfma": "16x16", "phase_occupancy": "2"}])
+def test_f32_drawn_ahead_chunks_equal_one_update_at_a_time(kw):
     """The 32-updates-per-graph path (batches drawn ahead and read in place, the critic's forward pass made
     one update ahead) makes bit for bit the updates that drawing a batch per update makes."""
     from d4pg_pytorch_amd.models.core import build_core
     from d4pg_pytorch_amd.replay.hbm_replay import HbmReplay
 
     def run(sample_ahead):
-        cfg = _cfg("d4pg", replay_mem_size=20_000, sample_ahead=sample_ahead)
+        cfg = _cfg("d4pg", replay_mem_size=20_000, sample_ahead=sample_ahead, **kw)
         core = build_core(cfg, "cuda")
+        assert core.lean == (kw.get("phase_occupancy") == "2")
         rp = HbmReplay(cfg, "cuda", core.dev_state)
         core.attach_replay(rp)
         g = torch.Generator().manual_seed(3)
