@@ -29,10 +29,11 @@ ACTOR = ["prologue", "cf1", "cf2", "cf3", "loss", "cb3", "cb2", "cb1", "ab3", "a
 def main():
     batch = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     dtype = sys.argv[2] if len(sys.argv) > 2 else "bf16"
-    # D4PG_STAMP_ENV / D4PG_STAMP_MFMA: another shape / the other set of fp32 phase kernels
+    # D4PG_STAMP_ENV / D4PG_STAMP_MFMA / D4PG_STAMP_OCC: another shape / the other set of fp32 phase kernels / workgroups per CU
     cfg = default_config(env=os.environ.get("D4PG_STAMP_ENV", "LunarLanderContinuous-v2"), model="d4pg", batch_size=batch,
                          device="cuda", v_min=-200.0, v_max=200.0, compute_dtype=dtype, replay_mem_size=100_000,
-                         phase_mfma=os.environ.get("D4PG_STAMP_MFMA", "auto"))
+                         phase_mfma=os.environ.get("D4PG_STAMP_MFMA", "auto"),
+                         phase_occupancy=os.environ.get("D4PG_STAMP_OCC", "auto"))
     core = build_core(cfg, "cuda")
     rp = HbmReplay(cfg, "cuda", core.dev_state)
     core.attach_replay(rp)

@@ -7,7 +7,8 @@
 //
 //   phases : v_mfma_f32_4x4x1_16b_f32 on tiles of 4 * MT rows (csrc/mlp32_dev.h; one instance per hidden-width
 //            class, KSH > 0) or v_mfma_f32_16x16x4_f32 on tiles of 8 / 16 rows (csrc/mlp16_dev.h; widths at run
-//            time, KSH = 0); weights streamed from fp32 copies packed in the fragment order of the path;
+//            time, KSH = 0; KSN = 1: its lean build, two workgroups per CU for grids of two workgroups per CU
+//            and more); weights streamed from fp32 copies packed in the fragment order of the path;
 //            activations, logits, losses, dX in fp32 in LDS
 //   wgrad  : v_mfma_f32_32x32x2_f32 on fp32 stashes written by the phases in operand-fragment order,
 //            Adam + Polyak + refresh of the packed copies fused into the tile epilogue
@@ -1455,7 +1456,8 @@ __global__ __launch_bounds__(64 * NWV) void wgrad32_kernel(const WgradGroup32 g)
     // Software pipeline over the wave's groups of 8 batch rows: WG_DEPTH operand pairs in flight.  (Left to the
     // compiler the loop is not unrolled and every iteration waits for its own two loads: with the stashes of a
     // 4096-row batch coming from beyond L2 the matrix pipe was 43 % busy.)  Loads past the wave's range re-read its
-    // last group and are not multiplied.
+    // last group and are not multiplied.  (Deeper does not help: 8 waves with 8, 12 or 16 pairs in flight each took
+    // 220 - 222 us per Ant update of 4096 rows where 16 waves with 4 take 216.6, bench/exp/r3_wgrad_depth.sh.)
     constexpr int WG_DEPTH = 4;
     f32x4 avq[WG_DEPTH], bvq[WG_DEPTH];
     const bool apply_only = g.apply_only != 0;      // (uniform over the launch)

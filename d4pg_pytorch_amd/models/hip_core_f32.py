@@ -16,7 +16,8 @@ f32 multiply-add on the matrix cores — and the launch structure of :class:`Hip
 ``csrc/fused32.hip``: two sets of phase kernels.  ``csrc/mlp32_dev.h``: ``v_mfma_f32_4x4x1_16b_f32`` on tiles of
 4 / 8 / 16 rows, one compiled instance per hidden-width class of 32 (64, 100 / 128, 200, 256, 300, 400, 512) — the fast
 one while an update is a latency-bound chain.  ``csrc/mlp16_dev.h``: ``v_mfma_f32_16x16x4_f32`` on tiles of 8 / 16 rows,
-every width at run time — for batches that fill the chip (from 4096 rows) and for every other hidden width.
+every width at run time — for batches that fill the chip (from 4096 rows, where a lean build of them keeps two workgroups
+on every CU: ``phase_occupancy``) and for every other hidden width.
 ``v_mfma_f32_32x32x2_f32`` in the weight gradients; weights are read from fp32 copies packed in the fragment order of
 the kernel set in use (``Shadow32Layout``), which the optimiser inside ``wgrad32`` keeps current.
 Everything else (drawn-ahead batches read in place, 32 updates per graph replay, critic forward made
@@ -24,6 +25,7 @@ ahead, prioritised draw riding in the last launch, checkpoints, data-parallel wi
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional
 
 import torch
@@ -37,7 +39,7 @@ LDS_PAD32 = 4
 #: batch size from which the 16x16x4 kernels (``csrc/mlp16_dev.h``, tiles of 16 rows) replace the 4x4x1 ones for the
 #: compiled widths (other widths always take them).  Measured, us per update, 4x4x1 / 16x16x4: Walker2d shape batch 1024
 #: 107 / 144, 2048 145 / 158 (128 tiles of 16 rows leave half the chip to the short roles of each launch), 4096
-#: 253 / 221; Ant shape batch 4096 301 / 238.
+#: 253 / 221 (202 with two workgroups per CU, LEAN_FROM_TILES); Ant shape batch 4096 301 / 238 (216).
 WIDE_FROM_BATCH = 4096
 #: row tiles from which the lean build of the 16x16x4 kernels runs (two workgroups per CU: at most 128 registers per
 #: lane and 80 KB of LDS per workgroup, tiles that are never live together sharing a buffer).  From here every phase
@@ -137,7 +139,6 @@ class HipCoreF32(HipCoreBf16):
         if self.lean:
             self._fn_critic, self._fn_actor = "d4pg_critic_phase32wl", "d4pg_actor_phase32wl"
             self.ahead_tiles = 256        # the critic's forward pass rides in the actor launch while both fit the chip twice
-            import os
             self.role_map = int(os.environ.get("D4PG_ROLE_MAP", "1")) if (B // 16) % 256 == 0 else 0
         self.refresh_shadows()
 
