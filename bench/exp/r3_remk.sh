@@ -1,0 +1,16 @@
+#!/bin/bash
+# 16x16x4 kernels: the one column tile beyond a multiple of 8 split along K over four waves (a 400-wide layer has 25 tiles)
+set -o pipefail
+O=gpurun_out/r3_remk
+mkdir -p $O
+cd "$GRAFT_REPO_ROOT"
+timeout -k 10 900 python -u -m pytest tests/test_hip_f32.py tests/test_gpu_rollout.py tests/test_replicated_dp.py -x -q --timeout 300 --timeout-method thread > $O/pytest.log 2>&1 || { tail -40 $O/pytest.log; exit 1; }
+tail -3 $O/pytest.log
+b() { name=$1; shift; timeout -k 10 150 python bench.py --no-bf16 --no-extras "$@" > $O/bench_$name.json 2> $O/bench_$name.err || { tail -3 $O/bench_$name.err; return 1; }; python -c "import json;d=json.load(open('$O/bench_$name.json'));print('$name', round(d['ms_per_step']*1000,2),'us')"; }
+b walker4096 --env Walker2d-v2 --batch 4096 --steps 800 --warmup 100 || exit 1
+b ant4096 --env Ant-v2 --batch 4096 --steps 800 --warmup 100 || exit 1
+b ant4096_occ1 --env Ant-v2 --batch 4096 --steps 800 --warmup 100 --occupancy 1 || exit 1
+b walker2048_16x16 --env Walker2d-v2 --batch 2048 --steps 1500 --warmup 200 --mfma 16x16 || exit 1
+b walker1024_16x16 --env Walker2d-v2 --batch 1024 --steps 1500 --warmup 200 --mfma 16x16 || exit 1
+b lunar256_16x16 --mfma 16x16 || exit 1
+b lunar256 || exit 1
