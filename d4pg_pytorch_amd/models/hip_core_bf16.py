@@ -162,7 +162,7 @@ class HipCoreBf16(HipCore):
         (instead of a tree update beside the actor phase, a sampling role in the update's last launch and a
         critic phase that makes its own forward pass).  ``D4PG_PER_AHEAD=0`` keeps the older scheme."""
         return (self.supports_per_ahead and self._per_sampling_rides_along()
-                and self.B // (self.rows_per_tile_unit * self.mt) <= 128
+                and self.B // (self.rows_per_tile_unit * self.mt) <= self.ahead_tiles
                 and bool(int(os.environ.get("D4PG_PER_AHEAD", "1"))) and bool(int(os.environ.get("D4PG_CRITIC_AHEAD", "1"))))
 
     def _write_dev_state(self, *args, **kw) -> None:

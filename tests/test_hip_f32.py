@@ -202,7 +202,9 @@ def test_f32_drawn_ahead_chunks_equal_one_update_at_a_time(kw):
     assert torch.equal(p1, p8) and torch.equal(t1, t8)
 
 
-def test_f32_ride_along_prioritised_draw_is_proportional():
+@pytest.mark.parametrize("kw,T", [({}, 240), ({"phase_mfma": "16x16", "phase_occupancy": "2"}, 240),
+                                  ({"batch_size": 4096}, 40)])      # 4096 rows: two workgroups per CU, roles dealt in runs of 256
+def test_f32_ride_along_prioritised_draw_is_proportional(kw, T):
     """Prioritised replay on the fused fp32 core: the batch of update k + 1 is drawn INSIDE update k (workgroups of the
     actor-phase launch, behind the priority write-back in the weight-gradient launch before it).  Distribution and
     importance weights of those draws against the tree they were made from: P(i) = p_i / sum p, w_i = (p_min / p_i)^beta
@@ -210,11 +212,12 @@ def test_f32_ride_along_prioritised_draw_is_proportional():
     from d4pg_pytorch_amd.models.core import build_core
     from d4pg_pytorch_amd.replay.hbm_replay import HbmReplay
     cfg = _cfg("d4pg", replay_mem_size=5000, replay_memory_prioritized=1, priority_beta_start=0.5, priority_beta_end=0.5,
-               sample_ahead=1)
+               sample_ahead=1, **kw)
     core = build_core(cfg, "cuda")
     rp = HbmReplay(cfg, "cuda", core.dev_state)
     core.attach_replay(rp)
     assert core._per_ahead(), "the configuration must take the ride-along draw (CriticAhead mode 3)"
+    assert core.lean == ("phase_occupancy" in kw or cfg["batch_size"] >= 4096)
     n = 3000
     g = torch.Generator().manual_seed(4)
     rows = torch.randn(n, rp.row_ld, generator=g)
@@ -222,7 +225,7 @@ def test_f32_ride_along_prioritised_draw_is_proportional():
     rows[:, rp.S + rp.A + 2] = 0.99 ** 5
     rp.insert(rows.cuda())
     rp.update_priorities(torch.arange(n), torch.rand(n, generator=g) * 5 + 0.01)      # a spread of priorities to start from
-    B, T = cfg["batch_size"], 240
+    B = cfg["batch_size"]
     torch.cuda.synchronize()
     leaf0 = rp.leaf[:n].cpu().double()
     counts = torch.zeros(n, dtype=torch.float64)
@@ -235,7 +238,7 @@ def test_f32_ride_along_prioritised_draw_is_proportional():
         assert ii.min() >= 0 and ii.max() < n
         counts += torch.bincount(ii, minlength=n).double()
         expected += B * leaf / leaf.sum()
-        if k % 60 == 0:
+        if k % (T // 4) == 0:
             want_w = (leaf.min() / leaf[ii]) ** 0.5
             torch.testing.assert_close(core.weights.cpu().double(), want_w, rtol=2e-4, atol=1e-6)
     assert counts.sum() == T * B
