@@ -1,6 +1,7 @@
 #!/bin/bash
 # Lean launches at 4096 rows: the short role of a launch starts some microseconds late, so that its hidden layer meets
-# the long role's loss rows instead of its hidden layers
+# the long role's loss rows instead of its hidden layers.  (D4PG_ROLE_DELAY_US / D4PG_AHEAD_DELAY_US drove a wait that was built
+# for this run only: every delay cost time, bench/exp/README.md; as the kernels are now the variables are ignored.)
 set -o pipefail
 O=gpurun_out/r3_delay
 mkdir -p $O
