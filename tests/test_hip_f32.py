@@ -51,7 +51,8 @@ CASES = [("d4pg", {}), ("d4pg", {"critic_loss": "ce", "dense_size": 128}), ("d3p
          ("d4pg", {"env": "BipedalWalker-v2", "phase_mfma": "16x16", "phase_occupancy": "2"}),
          ("d4pg", {"env": "Ant-v2", "phase_mfma": "16x16", "phase_occupancy": "2"}),          # logits where (s', a') was
          ("d3pg", {"env": "Walker2d-v2", "dense_size": 300, "batch_size": 512, "phase_mfma": "16x16", "phase_occupancy": "2"}),
-         ("d4pg", {"env": "Ant-v2", "batch_size": 4096})]                                     # what `auto` runs from 256 row tiles
+         ("d4pg", {"env": "Ant-v2", "batch_size": 4096}),                                     # what `auto` runs from 256 row tiles
+         ("d4pg", {"dense_size": 32}), ("d3pg", {"dense_size": 24, "env": "Pendulum-v0", "batch_size": 64})]   # every layer in K-slices
 
 def test_default_dtype_is_the_fused_fp32_pipeline():
     """``compute_dtype: auto`` is reference precision; shapes outside the fused kernels fall back to the
