@@ -115,6 +115,11 @@ __device__ __forceinline__ void mma_grp16(const f32x4& a, const Grp16<TP>& r, f3
 #endif
 constexpr int RING16 = D4PG_RING16;
 static_assert(RING16 >= 3 && RING16 <= 6, "two groups arrive prefetched; the ring holds them and at least one more");
+#ifndef D4PG_RING16_LEAN
+#define D4PG_RING16_LEAN 3
+#endif
+// ring depth by column tiles per pass (the lean build's groups are half as long in time)
+constexpr int ring16_of(int tp) { return tp == TPW16_LEAN ? D4PG_RING16_LEAN : RING16; }
 
 #ifdef D4PG_LDS_ASM      // A fragments by an explicit ds_read_b128 one group ahead of their use (the compiler sinks a plain
                          // LDS load to just in front of the first MFMA that needs it)
@@ -135,28 +140,29 @@ __device__ __forceinline__ void lds_frag16_wait() {}
 
 template <int T, int TP>
 __device__ __forceinline__ void pass16(const Unit16<TP>& u, const Pre16<TP>& t, const float* Al, f32x4 (&acc)[TP][2]) {
-    Grp16<TP> r[RING16];
+    constexpr int RING = ring16_of(TP);
+    Grp16<TP> r[RING];
     r[0] = t.g[0];
     r[1] = t.g[1];
 #pragma unroll
-    for (int j = 2; j < RING16 - 1; ++j) load_grp16<T>(r[j], u, u.g0 + j);
+    for (int j = 2; j < RING - 1; ++j) load_grp16<T>(r[j], u, u.g0 + j);
     const int last = u.g1 - 1;
     int g = u.g0;
     f32x4 a = lds_frag16(Al + 16 * g), an;
     lds_frag16_wait();
-    for (; g + RING16 <= u.g1; g += RING16) {
+    for (; g + RING <= u.g1; g += RING) {
 #pragma unroll
-        for (int s = 0; s < RING16; ++s) {
-            load_grp16<T>(r[(s + RING16 - 1) % RING16], u, g + s + RING16 - 1);
+        for (int s = 0; s < RING; ++s) {
+            load_grp16<T>(r[(s + RING - 1) % RING], u, g + s + RING - 1);
             an = lds_frag16(Al + 16 * min(g + s + 1, last));
             mma_grp16<T>(a, r[s], acc);
             lds_frag16_wait();
             a = an;
         }
     }
-    const int rem = u.g1 - g;      // 0 .. RING16 - 1 groups left, all loaded
+    const int rem = u.g1 - g;      // 0 .. RING - 1 groups left, all loaded
 #pragma unroll
-    for (int s = 0; s < RING16 - 1; ++s) {
+    for (int s = 0; s < RING - 1; ++s) {
         if (s < rem) {
             an = lds_frag16(Al + 16 * min(g + s + 1, last));
             mma_grp16<T>(a, r[s], acc);
