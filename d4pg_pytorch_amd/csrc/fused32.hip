@@ -671,11 +671,9 @@ __global__ __launch_bounds__(64 * NW32, lean_lds(KSH, KSN) ? 4 : 2) void critic_
     }, [&] { ch.template prefetch_n_if<0>(a.cf[0], !ahead_ok); });
     if (!ahead_ok) {
         // ---- online critic: (s, a) -> logits, activations stashed for wgrad ----
-        // (no barrier since the layer before: when BOTH are K-split, which takes a hidden width of at most 64 on the
-        // 16x16x4 path, the first layer here must not write its partial sums while a wave still reads the last ones)
-        if constexpr (KSH == 0) {
-            if (a.cf[0].ksplit > 1) __syncthreads();
-        }
+        // (no barrier since the layer before, whose K-slices met through `red`: on the 16x16x4 path the first layer
+        // here may put partial sums there as well, and must not while a wave still reads the last ones)
+        if constexpr (KSH == 0) __syncthreads();
         ch.template narrow<0>(xin, d.ldx, a.cf[0], [=](int r0, int col, f32x4 v) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);

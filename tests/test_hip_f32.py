@@ -102,7 +102,11 @@ def test_f32_gradients_match_autograd(model, kw):
                 a_, b_ = hg[k][off - net.base: off - net.base + n], tg[k][off - net.base: off - net.base + n]
                 if b_.norm() > 1e-10:
                     rel = ((a_ - b_).norm() / b_.norm()).item()
-                    assert rel < 2e-4, (k, off, rel)
+                    # (a gradient is discontinuous where a pre-activation is 0: which side of it a unit lands on is decided
+                    # by the order of an fp32 sum.  Among the 4096 x 400 activations of the largest case one or two units
+                    # differ from torch's for most seeds, each worth 1 - 3e-4 of a layer's gradient norm — the layers above
+                    # the unit, never the one below it: bench/exp/r3_remk_err.py prints the pattern)
+                    assert rel < (2e-4 if cfg["batch_size"] < 4096 else 6e-4), (k, off, rel)
 
 
 @pytest.mark.parametrize("model,kw", CASES)
