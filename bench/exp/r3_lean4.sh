@@ -1,6 +1,7 @@
 #!/bin/bash
-# Inputs of a phase in one round trip (issue / commit apart, tile copies with four loads in flight): the fp32 tests, then
-# the headline and the large batches
+# Inputs of a phase in one round trip (issue / commit apart, tile copies with four loads in flight) and the kernel bodies
+# behind two __global__ wrappers: the fp32 tests, then the headline and the large batches.  (Both were measured with this
+# script and not kept, bench/exp/README.md; what is left of them is copy16x4 in the lean build's mid-kernel tile copies.)
 set -o pipefail
 O=gpurun_out/r3_lean5
 mkdir -p $O
