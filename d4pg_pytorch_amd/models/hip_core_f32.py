@@ -16,8 +16,8 @@ f32 multiply-add on the matrix cores — and the launch structure of :class:`Hip
 ``csrc/fused32.hip``: two sets of phase kernels.  ``csrc/mlp32_dev.h``: ``v_mfma_f32_4x4x1_16b_f32`` on tiles of
 4 / 8 / 16 rows, one compiled instance per hidden-width class of 32 (64, 100 / 128, 200, 256, 300, 400, 512) — the fast
 one while an update is a latency-bound chain.  ``csrc/mlp16_dev.h``: ``v_mfma_f32_16x16x4_f32`` on tiles of 8 / 16 rows,
-every width at run time — for batches that fill the chip (from 4096 rows, where a lean build of them keeps two workgroups
-on every CU: ``phase_occupancy``) and for every other hidden width.
+every width at run time — for batches beyond 2048 rows (from 200 row tiles in a lean build that keeps two workgroups on
+every CU: ``phase_occupancy``) and for every other hidden width.
 ``v_mfma_f32_32x32x2_f32`` in the weight gradients; weights are read from fp32 copies packed in the fragment order of
 the kernel set in use (``Shadow32Layout``), which the optimiser inside ``wgrad32`` keeps current.
 Everything else (drawn-ahead batches read in place, 32 updates per graph replay, critic forward made
@@ -37,15 +37,18 @@ from .nets import LayerSlot, Packed32, Shadow32Layout, Shadow32Slot, pad16, pad3
 
 LDS_PAD32 = 4
 #: batch size from which the 16x16x4 kernels (``csrc/mlp16_dev.h``, tiles of 16 rows) replace the 4x4x1 ones for the
-#: compiled widths (other widths always take them).  Measured, us per update, 4x4x1 / 16x16x4: Walker2d shape batch 1024
-#: 107 / 144, 2048 145 / 158 (128 tiles of 16 rows leave half the chip to the short roles of each launch), 4096
-#: 253 / 221 (202 with two workgroups per CU, LEAN_FROM_TILES); Ant shape batch 4096 301 / 238 (216).
-WIDE_FROM_BATCH = 4096
+#: compiled widths (other widths always take them): beyond 2048 rows, where 8-row tiles no longer fit the 256 CUs in one
+#: round.  Measured, us per update, 4x4x1 / 16x16x4: Walker2d shape batch 1024 107 / 144, 2048 145 / 158 (128 tiles of
+#: 16 rows leave half the chip to the short roles of each launch), 2064 205 / 176, 2304 207 / 177, 2560 209 / 180,
+#: 3072 217 / 186, 3584 243 / 212 (193 with two workgroups per CU), 4096 253 / 221 (202); Ant shape 3072 254 / 198,
+#: 4096 301 / 238 (216).
+WIDE_FROM_BATCH = 2049
 #: row tiles from which the lean build of the 16x16x4 kernels runs (two workgroups per CU: at most 128 registers per
-#: lane and 80 KB of LDS per workgroup, tiles that are never live together sharing a buffer).  From here every phase
-#: launch holds at least two workgroups for each of the 256 CUs, and the second one multiplies while the first loads
-#: rows, reduces K-slices or computes loss rows.
-LEAN_FROM_TILES = 256
+#: lane and 80 KB of LDS per workgroup, tiles that are never live together sharing a buffer): the second workgroup of a
+#: CU multiplies while the first loads rows, reduces K-slices or computes loss rows.  Measured, one / two workgroups per
+#: CU: 160 tiles 179.7 / 179.5 us, 192 tiles 185.9 / 186.1, 200 tiles 207.8 / 188.5, 224 tiles 211.9 / 193.3,
+#: 256 tiles 222.9 / 201.8, 512 tiles 416 / 358.
+LEAN_FROM_TILES = 193
 
 
 class HipCoreF32(HipCoreBf16):
