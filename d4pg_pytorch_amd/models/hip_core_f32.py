@@ -41,8 +41,10 @@ LDS_PAD32 = 4
 #: round.  Measured, us per update, 4x4x1 / 16x16x4: Walker2d shape batch 1024 107 / 144, 2048 145 / 158 (128 tiles of
 #: 16 rows leave half the chip to the short roles of each launch), 2064 205 / 176, 2304 207 / 177, 2560 209 / 180,
 #: 3072 217 / 186, 3584 243 / 212 (193 with two workgroups per CU), 4096 253 / 221 (202); Ant shape 3072 254 / 198,
-#: 4096 301 / 238 (216).
+#: 4096 301 / 238 (216).  With the 4 input chunks of the Ant shape (119 inputs) the 4x4x1 kernels lose at 2048 rows
+#: already (1024: 123 / 152, 2048: 175 / 165): WIDE_FROM_BATCH_WIDE_INPUT.
 WIDE_FROM_BATCH = 2049
+WIDE_FROM_BATCH_WIDE_INPUT = 2048
 #: row tiles from which the lean build of the 16x16x4 kernels runs (two workgroups per CU: at most 128 registers per
 #: lane and 80 KB of LDS per workgroup, tiles that are never live together sharing a buffer): the second workgroup of a
 #: CU multiplies while the first loads rows, reduces K-slices or computes loss rows.  Measured, one / two workgroups per
@@ -78,7 +80,8 @@ class HipCoreF32(HipCoreBf16):
         want = str(cfg.get("phase_tile_rows", "auto"))
         mfma = str(cfg.get("phase_mfma", "auto"))          # auto | 4x4 | 16x16
         if mfma == "auto":
-            self.wide = (not narrow_ok) or (B >= WIDE_FROM_BATCH and B % 16 == 0 and want in ("auto", "16"))
+            wide_from = WIDE_FROM_BATCH_WIDE_INPUT if pad32(S + A) >= 128 else WIDE_FROM_BATCH
+            self.wide = (not narrow_ok) or (B >= wide_from and B % 16 == 0 and want in ("auto", "16"))
         else:
             self.wide = mfma == "16x16"
         if not self.wide and not narrow_ok:
