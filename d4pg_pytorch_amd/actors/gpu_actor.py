@@ -23,12 +23,19 @@ from __future__ import annotations
 from typing import Optional
 
 import numpy as np
+import os
+
 import torch
 
 from ..models.nets import NetLayout, NetView, Packed32, pad4, pad16, pad32
 from ..ops import hip as H
 
 LDS_PAD32 = 4
+#: states per launch from which the policy runs on the 16x16x4 kernel, as the learner's phases do (models/hip_core_f32.py):
+#: beyond 2048 the 4x4x1 kernel is on 16-row tiles.  Measured, whole rollout steps (policy + noise + environment) of the
+#: lunar lander, 4x4x1 / 16x16x4 policy kernel: 2048 environments 27.4 / 29.1 us, 4096: 40.4 / 30.4, 8192: 68.0 / 47.4;
+#: Walker2d 4096: 72.7 / 63.1 (bench/exp/r3_infer_wide.py).  D4PG_INFER_WIDE_FROM overrides it for A/B runs.
+WIDE_INFER_FROM_ROWS = 2049
 
 
 def has_narrow_kernels(hidden: int) -> bool:
@@ -40,14 +47,16 @@ class PackedActor32:
     """Packed fp32 copies of the three actor layers + biases in one device buffer, and the launch
     descriptor of the single-launch inference kernel."""
 
-    def __init__(self, state_dim: int, action_dim: int, hidden: int, device):
+    def __init__(self, state_dim: int, action_dim: int, hidden: int, device, rows: int = 1):
+        """``rows``: how many states a launch will usually take (decides between the two kernel sets)."""
         self.S, self.A, self.Hd = state_dim, action_dim, hidden
         self.device = torch.device(device)
         self.layout = NetLayout.build(state_dim, hidden, action_dim)
         waves = H.lib().d4pg_phase32_waves()
         # hidden widths the 4x4x1 kernels are compiled for take them; every other width the 16x16x4 kernel
         # (csrc/mlp16_dev.h: any width at run time, tiles of 8 / 16 environments)
-        self.wide = not (has_narrow_kernels(hidden) and pad32(state_dim) <= 128)
+        self.wide = not (has_narrow_kernels(hidden) and pad32(state_dim) <= 128) or \
+            (rows >= int(os.environ.get("D4PG_INFER_WIDE_FROM", WIDE_INFER_FROM_ROWS)) and rows % 16 == 0)
         off = 0
         self.packed = []
         for i, s in enumerate(self.layout.layers):
@@ -134,7 +143,7 @@ class GpuActor:
         self._x_host = torch.zeros(self.E, ldx).pin_memory()
         self._out_host = torch.zeros(self.E, lda).pin_memory()
         self._flat_host = torch.zeros(self.layout.numel).pin_memory()
-        self.fused = PackedActor32(state_dim, action_dim, hidden, self.device) \
+        self.fused = PackedActor32(state_dim, action_dim, hidden, self.device, rows=self.E) \
             if PackedActor32.supported(state_dim, action_dim, hidden) else None
         if self.fused is None:         # per-layer path: two hidden activation buffers
             self.h1 = torch.zeros(self.E, ldh, device=self.device)

@@ -41,7 +41,7 @@ class DeviceRollout:
         assert env.state_dim == self.S and env.action_dim == self.A
         if not PackedActor32.supported(self.S, self.A, int(cfg["dense_size"])):
             raise ValueError("the device rollout needs a policy the single-launch inference kernel supports (<= 64 actions)")
-        self.actor = PackedActor32(self.S, self.A, int(cfg["dense_size"]), self.device)
+        self.actor = PackedActor32(self.S, self.A, int(cfg["dense_size"]), self.device, rows=self.E)
         self.explore = bool(explore)
         self.n, self.gamma = int(cfg["n_step_returns"]), float(cfg["discount_rate"])
         if self.explore and float(cfg["ou_min_sigma"]) != float(cfg["ou_max_sigma"]):

@@ -25,14 +25,15 @@ def _torch_policy(pol, x):
 
 @pytest.mark.parametrize("S,A,Hd,E", [(24, 4, 400, 48), (3, 1, 400, 1), (8, 2, 128, 37), (17, 6, 256, 1500),
                                       (111, 8, 400, 4100), (24, 4, 72, 9), (17, 6, 300, 700), (8, 2, 1024, 40),
-                                      (17, 6, 180, 700), (8, 2, 64, 130), (8, 2, 512, 40), (3, 1, 200, 256)])
+                                      (17, 6, 180, 700), (8, 2, 64, 130), (8, 2, 512, 40), (3, 1, 200, 256),
+                                      (17, 6, 400, 4096)])      # beyond 2048 states: the 16x16x4 kernel for every width
 def test_gpu_actor_single_launch_matches_fp32_reference(S, A, Hd, E):
     from d4pg_pytorch_amd.actors.gpu_actor import GpuActor
     pol = _policy(S, A, Hd)
     gpu = GpuActor(S, A, Hd, max_batch=E, action_scale=1.5)
     gpu.load_flat(pol.flat.numpy())
     assert gpu.launches_per_act == 1          # every width: the 16x16x4 kernel takes what the 4x4x1 kernels are not built for
-    assert gpu.fused.wide == (Hd in (72, 180, 1024))
+    assert gpu.fused.wide == (Hd in (72, 180, 1024) or (E > 2048 and E % 16 == 0))
     x = torch.randn(E, S, generator=torch.Generator().manual_seed(2))
     want = 1.5 * _torch_policy(pol, x.double().float())
     got = gpu.act(x.numpy())
