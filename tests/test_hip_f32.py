@@ -70,6 +70,16 @@ def test_default_dtype_is_the_fused_fp32_pipeline():
     for width in (64, 100, 200, 256, 300, 400, 512):                # compile-time 4x4x1 kernels for the usual widths
         assert not build_core(_cfg("d4pg", dense_size=width), "cuda").wide, width
     assert build_core(_cfg("d4pg", dense_size=1024, batch_size=64), "cuda").wide
+    # which kernels a batch size gets: 4x4x1 up to 2048 rows (a multiple of 16 beyond that: 16x16x4), with inputs as wide as
+    # the Ant's from 2048; two workgroups per CU from 200 row tiles of 16
+    for kw, wide, lean in (({"batch_size": 2048}, False, False), ({"batch_size": 2064}, True, False),
+                           ({"batch_size": 3072}, True, False), ({"batch_size": 3200}, True, True),
+                           ({"batch_size": 4096}, True, True), ({"batch_size": 4096, "phase_occupancy": "1"}, True, False),
+                           ({"batch_size": 2048, "env": "Ant-v2"}, True, False), ({"batch_size": 1024, "env": "Ant-v2"}, False, False),
+                           ({"batch_size": 4096, "dense_size": 512}, True, False)):      # 16-row tiles of 512 columns: > 80 KB
+        c = build_core(_cfg("d4pg", **kw), "cuda")
+        assert (c.wide, c.lean) == (wide, lean), (kw, c.wide, c.lean)
+        del c
     assert type(build_core(_cfg("d4pg", num_atoms=101), "cuda")) is HipCore      # more atoms than a wavefront has lanes
     assert type(build_core(_cfg("d4pg", fused_learner="layers"), "cuda")) is HipCore
     bf = build_core(_cfg("d4pg", compute_dtype="bf16"), "cuda")
