@@ -117,7 +117,8 @@ class HipCoreF32(HipCoreBf16):
         # height, until the MFMA work of the tile (2.3 us per 400 x 400 layer and 4 rows) exceeds it: 4-row
         # tiles while their workgroups (critic + actor forward) fit the 256 CUs, taller tiles beyond.  Measured
         # (us per update, 4 / 8 / 16 rows): batch 512: 86 / 96 / -, 1024: 117 / 105 / -, 2048: 205 / 147 / 186,
-        # 4096 (Ant): 451 / 329 / 311  (bench/exp/ab_tile32.sh).
+        # 4096 (Ant): 451 / 329 / 311  (bench/exp/ab_tile32.sh).  In between, Walker2d shape, 4 / 8 rows: 640: 97.7 / 103.8,
+        # 768: 99.3 / 104.4, 896: 112.8 / 106.1 (bench/exp/r3_tile_sweep.sh): 4-row tiles up to 192 of them per role.
         lds_fn = H.lib().d4pg_phase32w_lds_bytes if self.wide else H.lib().d4pg_phase32_lds_bytes
 
         def lds_need(mt: int) -> int:
@@ -129,7 +130,7 @@ class HipCoreF32(HipCoreBf16):
         elif want in ("4", "8", "16"):
             self.mt = int(want) // 4
         else:
-            self.mt = 1 if B // 4 <= 128 else (2 if B // 8 <= 256 else 4)
+            self.mt = 1 if B // 4 <= 192 else (2 if B // 8 <= 256 else 4)
         while not self.wide and self.mt > 1 and B % (4 * self.mt):
             self.mt //= 2
         need = lds_need(self.mt)
