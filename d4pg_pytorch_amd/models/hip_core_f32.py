@@ -16,8 +16,8 @@ f32 multiply-add on the matrix cores — and the launch structure of :class:`Hip
 ``csrc/fused32.hip``: two sets of phase kernels.  ``csrc/mlp32_dev.h``: ``v_mfma_f32_4x4x1_16b_f32`` on tiles of
 4 / 8 / 16 rows, one compiled instance per hidden-width class of 32 (64, 100 / 128, 200, 256, 300, 400, 512) — the fast
 one while an update is a latency-bound chain.  ``csrc/mlp16_dev.h``: ``v_mfma_f32_16x16x4_f32`` on tiles of 8 / 16 rows,
-every width at run time — for batches beyond 2048 rows (from 200 row tiles in a lean build that keeps two workgroups on
-every CU: ``phase_occupancy``) and for every other hidden width.
+every width at run time — for batches beyond 2048 rows (in a lean build that keeps two workgroups on every CU:
+``phase_occupancy``) and for every other hidden width.
 ``v_mfma_f32_32x32x2_f32`` in the weight gradients; weights are read from fp32 copies packed in the fragment order of
 the kernel set in use (``Shadow32Layout``), which the optimiser inside ``wgrad32`` keeps current.
 Everything else (drawn-ahead batches read in place, 32 updates per graph replay, critic forward made
@@ -46,11 +46,14 @@ LDS_PAD32 = 4
 WIDE_FROM_BATCH = 2049
 WIDE_FROM_BATCH_WIDE_INPUT = 2048
 #: row tiles from which the lean build of the 16x16x4 kernels runs (two workgroups per CU: at most 128 registers per
-#: lane and 80 KB of LDS per workgroup, tiles that are never live together sharing a buffer): the second workgroup of a
-#: CU multiplies while the first loads rows, reduces K-slices or computes loss rows.  Measured, one / two workgroups per
-#: CU: 160 tiles 179.7 / 179.5 us, 192 tiles 185.9 / 186.1, 200 tiles 207.8 / 188.5, 224 tiles 211.9 / 193.3,
-#: 256 tiles 222.9 / 201.8, 512 tiles 416 / 358.
-LEAN_FROM_TILES = 193
+#: lane and 80 KB of LDS per workgroup, tiles that are never live together sharing a buffer): as soon as a launch holds
+#: more workgroups than the chip has CUs.  The second workgroup of a CU multiplies while the first loads rows, reduces
+#: K-slices or computes loss rows.  Measured, one / two workgroups per CU, width 400: 128 tiles (Ant) 165.7 / 173.3 us,
+#: 129 tiles 175.9 / 175.1, 160 tiles 179.7 / 179.5, 192 tiles 185.9 / 186.1, 200 tiles 207.8 / 188.5, 224 tiles
+#: 211.9 / 193.3, 256 tiles 222.9 / 201.8, 512 tiles 416 / 358; width 300: 129 tiles 139.5 / 132.9, 256 tiles
+#: 177.5 / 159.8; width 256: 160 tiles 127.2 / 115.7, 256 tiles 160.3 / 134.9; width 128: 160 tiles 103.4 / 91.1,
+#: 256 tiles 134.0 / 107.7.
+LEAN_FROM_TILES = 129
 
 
 class HipCoreF32(HipCoreBf16):

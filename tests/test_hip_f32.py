@@ -71,9 +71,9 @@ def test_default_dtype_is_the_fused_fp32_pipeline():
         assert not build_core(_cfg("d4pg", dense_size=width), "cuda").wide, width
     assert build_core(_cfg("d4pg", dense_size=1024, batch_size=64), "cuda").wide
     # which kernels a batch size gets: 4x4x1 up to 2048 rows (a multiple of 16 beyond that: 16x16x4), with inputs as wide as
-    # the Ant's from 2048; two workgroups per CU from 200 row tiles of 16
-    for kw, wide, lean in (({"batch_size": 2048}, False, False), ({"batch_size": 2064}, True, False),
-                           ({"batch_size": 3072}, True, False), ({"batch_size": 3200}, True, True),
+    # the Ant's from 2048; two workgroups per CU as soon as a launch holds more workgroups than the chip has CUs
+    for kw, wide, lean in (({"batch_size": 2048}, False, False), ({"batch_size": 2064}, True, True),
+                           ({"batch_size": 3072}, True, True), ({"batch_size": 3200}, True, True),
                            ({"batch_size": 4096}, True, True), ({"batch_size": 4096, "phase_occupancy": "1"}, True, False),
                            ({"batch_size": 2048, "env": "Ant-v2"}, True, False), ({"batch_size": 1024, "env": "Ant-v2"}, False, False),
                            ({"batch_size": 4096, "dense_size": 512}, True, False)):      # 16-row tiles of 512 columns: > 80 KB
