@@ -1263,7 +1263,7 @@ constexpr int LEAN_LDS_LIMIT = 81920;
 static int critic_phase32w(const CriticPhaseArgs32* a, int mt, bool lean, hipStream_t stream) {
     const PhaseDims& d = a->d;
     if (mt != 2 && mt != 4) return -9;
-    if (lean && (mt != 4 || lds_bytes_critic32(d, 16, 4, true, true) > LEAN_LDS_LIMIT)) return -17;
+    if (lean && mt != 4) return -17;      // (beyond LEAN_LDS_LIMIT it runs as one workgroup per CU; launch_phase bounds the size)
     const int M = 4 * mt;
     if (int rc = check_dims16(d, M)) return rc;
     const LayerW32* nets[4] = {a->ta, a->tc, a->cf, a->fwd.af};
@@ -1290,7 +1290,7 @@ D4PG_API int d4pg_critic_phase32wl(const CriticPhaseArgs32* a, int mt, hipStream
 static int actor_phase32w(const ActorPhaseArgs32* a, int mt, bool lean, hipStream_t stream) {
     const PhaseDims& d = a->d;
     if (mt != 2 && mt != 4) return -9;
-    if (lean && (mt != 4 || lds_bytes_actor32(d, 16, 4, true, true) > LEAN_LDS_LIMIT)) return -17;
+    if (lean && mt != 4) return -17;
     const int M = 4 * mt;
     if (int rc = check_dims16(d, M)) return rc;
     if (int rc = check_layer16(a->cf[0], d.ldx)) return rc;

@@ -54,6 +54,12 @@ WIDE_FROM_BATCH_WIDE_INPUT = 2048
 #: 177.5 / 159.8; width 256: 160 tiles 127.2 / 115.7, 256 tiles 160.3 / 134.9; width 128: 160 tiles 103.4 / 91.1,
 #: 256 tiles 134.0 / 107.7.
 LEAN_FROM_TILES = 129
+#: 8-row tiles beyond which a network too wide for four 16-row tiles of LDS (widths from ~530: the one-workgroup build
+#: then runs 8-row tiles, half of every MFMA spent on copies) runs the lean build on 16-row tiles, as one workgroup per CU
+#: (its two shared tiles fit up to ~1000 columns).  Measured, us per update, 8-row / 16-row tiles, Walker2d shape:
+#: width 768: 256 rows 322 / 330, 1024: 349 / 354, 2048: 482 / 390, 4096: 926 / 558; width 1024: 256 rows 499 / 531,
+#: 1024: 553 / 582, 2048: 766 / 644, 4096: 1474 / 922.
+LEAN_ONLY_FROM_TILES8 = 255
 
 
 class HipCoreF32(HipCoreBf16):
@@ -126,30 +132,35 @@ class HipCoreF32(HipCoreBf16):
 
         def lds_need(mt: int) -> int:
             return max(lds_fn(self.dims, mt, 0), lds_fn(self.dims, mt, 1))
+        occ = str(cfg.get("phase_occupancy", "auto"))      # the lean build: auto | 1 | 2 (workgroups per CU)
+        lean_need, lean_only = 0, False
         if self.wide:
             # 16 rows use every row of the MFMA; 8 rows (half of each instruction spent on copies) where 16 do not
-            # divide the batch or four 16-row hidden tiles do not fit the LDS (widths beyond ~470)
-            self.mt = 2 if (want == "8" or B % 16 or lds_need(4) > LDS_LIMIT) else 4
+            # divide the batch or four 16-row hidden tiles do not fit the LDS (widths beyond ~470).  The lean build
+            # keeps two such tiles, not four: widths up to ~1000 fit on 16-row tiles there, as one workgroup per CU.
+            lean_need = max(H.lib().d4pg_phase32wl_lds_bytes(self.dims, 0), H.lib().d4pg_phase32wl_lds_bytes(self.dims, 1))
+            rows16 = want != "8" and B % 16 == 0
+            lean_only = rows16 and lds_need(4) > LDS_LIMIT and lean_need <= LDS_LIMIT and occ != "1" and \
+                (occ == "2" or B // 8 > int(os.environ.get("D4PG_LEAN_ONLY_FROM_TILES8", LEAN_ONLY_FROM_TILES8)))
+            self.mt = 4 if rows16 and (lds_need(4) <= LDS_LIMIT or lean_only) else 2
         elif want in ("4", "8", "16"):
             self.mt = int(want) // 4
         else:
             self.mt = 1 if B // 4 <= 192 else (2 if B // 8 <= 256 else 4)
         while not self.wide and self.mt > 1 and B % (4 * self.mt):
             self.mt //= 2
-        need = lds_need(self.mt)
+        need = lean_need if lean_only else lds_need(self.mt)
         if need > LDS_LIMIT:
             raise ShapeLimit(f"dense_size={Hd} needs {need} bytes of LDS per workgroup (> {LDS_LIMIT})")
-        # the lean build: phase_occupancy: auto | 1 | 2 (workgroups per CU)
-        occ = str(cfg.get("phase_occupancy", "auto"))
-        lean_fits = self.wide and self.mt == 4 and max(H.lib().d4pg_phase32wl_lds_bytes(self.dims, 0),
-                                                       H.lib().d4pg_phase32wl_lds_bytes(self.dims, 1)) <= H.lib().d4pg_phase32wl_lds_limit()
-        if occ == "2" and not lean_fits:
-            raise ShapeLimit("phase_occupancy: 2 needs the 16x16x4 kernels on 16-row tiles and <= 80 KB of LDS per workgroup")
-        self.lean = lean_fits and (occ == "2" or (occ == "auto" and B // 16 >= LEAN_FROM_TILES))
+        lean_two = self.wide and self.mt == 4 and lean_need <= H.lib().d4pg_phase32wl_lds_limit()      # two workgroups fit a CU
+        if occ == "2" and not (lean_two or lean_only):
+            raise ShapeLimit("phase_occupancy: 2 needs the 16x16x4 kernels on 16-row tiles of at most 160 KB of LDS")
+        self.lean = lean_only or (lean_two and (occ == "2" or (occ == "auto" and B // 16 >= LEAN_FROM_TILES)))
         if self.lean:
             self._fn_critic, self._fn_actor = "d4pg_critic_phase32wl", "d4pg_actor_phase32wl"
-            self.ahead_tiles = 256        # the critic's forward pass rides in the actor launch while both fit the chip twice
-            self.role_map = int(os.environ.get("D4PG_ROLE_MAP", "1")) if (B // 16) % 256 == 0 else 0
+            if lean_two:
+                self.ahead_tiles = 256        # the critic's forward pass rides in the actor launch while both fit the chip twice
+                self.role_map = int(os.environ.get("D4PG_ROLE_MAP", "1")) if (B // 16) % 256 == 0 else 0
         self.refresh_shadows()
 
     # ------------------------------------------------------------------ shadows

@@ -52,7 +52,8 @@ CASES = [("d4pg", {}), ("d4pg", {"critic_loss": "ce", "dense_size": 128}), ("d3p
          ("d4pg", {"env": "Ant-v2", "phase_mfma": "16x16", "phase_occupancy": "2"}),          # logits where (s', a') was
          ("d3pg", {"env": "Walker2d-v2", "dense_size": 300, "batch_size": 512, "phase_mfma": "16x16", "phase_occupancy": "2"}),
          ("d4pg", {"env": "Ant-v2", "batch_size": 4096}),                                     # what `auto` runs from 256 row tiles
-         ("d4pg", {"dense_size": 32}), ("d3pg", {"dense_size": 24, "env": "Pendulum-v0", "batch_size": 64})]   # every layer in K-slices
+         ("d4pg", {"dense_size": 32}), ("d3pg", {"dense_size": 24, "env": "Pendulum-v0", "batch_size": 64}),   # every layer in K-slices
+         ("d4pg", {"dense_size": 768, "batch_size": 2048, "env": "Walker2d-v2"})]             # lean build, one workgroup per CU (> 80 KB)
 
 def test_default_dtype_is_the_fused_fp32_pipeline():
     """``compute_dtype: auto`` is reference precision; shapes outside the fused kernels fall back to the
@@ -76,7 +77,9 @@ def test_default_dtype_is_the_fused_fp32_pipeline():
                            ({"batch_size": 3072}, True, True), ({"batch_size": 3200}, True, True),
                            ({"batch_size": 4096}, True, True), ({"batch_size": 4096, "phase_occupancy": "1"}, True, False),
                            ({"batch_size": 2048, "env": "Ant-v2"}, True, False), ({"batch_size": 1024, "env": "Ant-v2"}, False, False),
-                           ({"batch_size": 4096, "dense_size": 512}, True, False)):      # 16-row tiles of 512 columns: > 80 KB
+                           ({"batch_size": 4096, "dense_size": 512}, True, False),       # 16-row tiles of 512 columns: > 80 KB
+                           # too wide for four 16-row tiles: 8-row tiles, or from 2048 rows the lean build's two, one workgroup per CU
+                           ({"batch_size": 1024, "dense_size": 768}, True, False), ({"batch_size": 2048, "dense_size": 768}, True, True)):
         c = build_core(_cfg("d4pg", **kw), "cuda")
         assert (c.wide, c.lean) == (wide, lean), (kw, c.wide, c.lean)
         del c
