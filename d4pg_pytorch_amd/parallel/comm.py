@@ -178,7 +178,7 @@ class TorchDistComm(Comm):
 
 #: One GPU, us per update by batch size (Walker2d shape, ``profiles/README.md``): what a rank of the replicated mode pays
 #: for the GLOBAL batch, and a rank of the gradient-exchange mode for its LOCAL batch.
-UPDATE_US = {"fp32": {256: 78.0, 512: 86.0, 1024: 106.0, 2048: 145.0, 4096: 221.0},
+UPDATE_US = {"fp32": {256: 78.0, 512: 86.0, 768: 99.0, 1024: 107.0, 2048: 144.0, 2064: 175.0, 3072: 186.0, 4096: 202.0, 8192: 358.0},
              "bf16": {256: 52.0, 512: 55.0, 1024: 59.0, 2048: 64.0, 4096: 90.0, 8192: 131.0}}
 #: what the gradient-exchange mode costs on top of the update and its two all-reduces (two more launches that apply the
 #: summed gradients, gradients through memory): measured over a world of one, where an in-graph RCCL all-reduce is no

@@ -122,17 +122,17 @@ def test_dp_mode_auto_follows_the_measured_all_reduce_time():
     + the stand-alone optimiser kernels."""
     from d4pg_pytorch_amd.parallel.comm import EXCHANGE_OVERHEAD_US, resolve_dp_mode, update_us
     assert update_us(256) == 78.0 and update_us(128) == 78.0
-    assert update_us(768) == pytest.approx((86.0 + 106.0) / 2)
-    assert update_us(8192) == pytest.approx(2 * 221.0)                     # linear in the batch past the table
-    # headline shape, 8 ranks x 256 rows: replicated 2048 rows = 145 us; exchange = 78 + 8 + 2 t
-    assert resolve_dp_mode("auto", 256, 8, "fp32", allreduce_us=25.0) == "grad_allreduce"      # 136 < 145
-    assert resolve_dp_mode("auto", 256, 8, "fp32", allreduce_us=35.0) == "replicated"          # 156 > 145
+    assert update_us(640) == pytest.approx((86.0 + 99.0) / 2)
+    assert update_us(16384) == pytest.approx(2 * 358.0)                    # linear in the batch past the table
+    # headline shape, 8 ranks x 256 rows: replicated 2048 rows = 144 us; exchange = 78 + 8 + 2 t
+    assert resolve_dp_mode("auto", 256, 8, "fp32", allreduce_us=25.0) == "grad_allreduce"      # 136 < 144
+    assert resolve_dp_mode("auto", 256, 8, "fp32", allreduce_us=35.0) == "replicated"          # 156 > 144
     # a slow fabric (gloo over loopback: milliseconds) replicates even batches the static limit would exchange
     assert resolve_dp_mode("auto", 4096, 8, "fp32") == "grad_allreduce"
     assert resolve_dp_mode("auto", 4096, 8, "fp32", allreduce_us=5000.0) == "replicated"
     # and a fast one exchanges where the static limit would replicate
     assert resolve_dp_mode("auto", 1024, 2, "fp32") == "replicated"
-    assert resolve_dp_mode("auto", 1024, 2, "fp32", allreduce_us=5.0) == "grad_allreduce"      # 106 + 8 + 10 < 145
+    assert resolve_dp_mode("auto", 1024, 2, "fp32", allreduce_us=5.0) == "grad_allreduce"      # 107 + 8 + 10 < 144
     # bf16 at 8 x 256: the update itself is so cheap (64 us for 2048 rows) that only an all-reduce under 2.5 us would pay
     t_break = (update_us(2048, "bf16") - update_us(256, "bf16") - EXCHANGE_OVERHEAD_US["bf16"]) / 2
     assert 0 < t_break < 5
