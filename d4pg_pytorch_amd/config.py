@@ -125,7 +125,7 @@ EXTENSION_DEFAULTS: Dict[str, Any] = {
     "dp_optimizer": "tiles",         # gradient-exchange mode: "tiles" = the weight-gradient kernel applies the summed gradients tile by tile, "flat" = the element-wise optimiser kernel (csrc/optim.hip)
     "phase_mfma": "auto",            # fp32 phase kernels: "auto" | "4x4" (v_mfma_f32_4x4x1, compiled widths) | "16x16" (v_mfma_f32_16x16x4, any width)
     "phase_tile_rows": "auto",       # batch rows per phase workgroup: "auto" | 4 | 8 | 16 (fp32) | 16 | 32 (bf16)
-    "phase_occupancy": "auto",       # fp32 16x16x4 phase kernels, workgroups per CU: "auto" | 1 | 2 (2: the lean build, <= 128 registers and 80 KB of LDS; auto: from 129 row tiles of 16)
+    "phase_occupancy": "auto",       # fp32 16x16x4 phase kernels: "auto" | 1 | 2.  2: the lean build (<= 128 registers, LDS tiles sharing buffers; two workgroups per CU where its LDS fits twice); 1: never; auto: from 129 row tiles of 16, and for networks too wide for four 16-row LDS tiles from 2048 rows
     "sample_ahead": 32,              # uniform replay, fused pipelines: batches drawn per sampling launch = updates per
                                      # graph replay (1: every update); 8: 55.3 us per update, 32: 54.4 us
     # --- lifecycle ---
